@@ -1,0 +1,467 @@
+"""CPU restatement of SPOT's tracker forward/backward hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the parity oracle.  It is imported by tests/, by
+__graft_entry__.smoke() and by bench.py's cpu_baseline leg, and by nothing
+else: the product path (spot_amd/) never imports it and has no CPU fallback.
+
+Every function restates, in plain functional torch-CPU / numpy arithmetic on a
+state dict, what one piece of the reference computes, and cites the reference
+file:line it follows (paths relative to the reference checkout).  The oracle is
+pinned: tests/test_oracle_golden.py checks every function here against golden
+vectors produced by running the reference itself (tests/golden/make_golden.py).
+
+Layout conventions: images NCHW; token tensors batch-first [B, L, C] (the
+reference uses [L, B, C]; the permutation is applied at the boundaries only).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# pre-input (ltr/models/pre_input/necessary_preprocess.py:24-39,54-67,86-91)
+# --------------------------------------------------------------------------
+def preprocess(images_u8, avg, mean, std, brightness=None):
+    """uint8 crop -> float, * brightness/255, clamp [0,1], (x-mean)/std; same on avg."""
+    B = images_u8.shape[0]
+    if brightness is None:
+        brightness = torch.ones(B)
+    f = (brightness / 255.0).to(torch.float32)
+    m = torch.as_tensor(mean, dtype=torch.float32).view(1, -1, 1, 1)
+    s = torch.as_tensor(std, dtype=torch.float32).view(1, -1, 1, 1)
+    img = (images_u8.float() * f[:, None, None, None]).clamp(0.0, 1.0)
+    img = (img - m) / s
+    a = (avg.float() * f[:, None]).clamp(0.0, 1.0)
+    a = (a - m.view(1, -1)) / s.view(1, -1)
+    return img, a
+
+
+# --------------------------------------------------------------------------
+# sine position encoding (ltr/models/neck/position_encoding.py:27-45)
+# --------------------------------------------------------------------------
+def position_embedding_sine(mask, num_pos_feats=128, temperature=10000.0):
+    """mask [B,H,W] bool (True = padded) -> pos [B, 2*num_pos_feats, H, W]."""
+    not_mask = (~mask).to(torch.float32)
+    y = not_mask.cumsum(1)
+    x = not_mask.cumsum(2)
+    eps, scale = 1e-6, 2 * math.pi
+    y = y / (y[:, -1:, :] + eps) * scale
+    x = x / (x[:, :, -1:] + eps) * scale
+    i = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / num_pos_feats)
+    px = x[..., None] / dim_t
+    py = y[..., None] / dim_t
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3).permute(0, 3, 1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------
+# backbone: ResNet-50 to layer3 (ltr/models/backbone/resnet.py:56-92,95-112,174-203)
+# --------------------------------------------------------------------------
+def _bn(x, sd, p, training):
+    return F.batch_norm(x, None if training else sd[p + ".running_mean"],
+                        None if training else sd[p + ".running_var"],
+                        sd[p + ".weight"], sd[p + ".bias"], training=training, eps=1e-5)
+
+
+def _bottleneck(x, sd, p, stride, dilation, training):
+    out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"]), sd, p + ".bn1", training))
+    out = F.conv2d(out, sd[p + ".conv2.weight"], stride=stride, padding=dilation, dilation=dilation)
+    out = F.relu(_bn(out, sd, p + ".bn2", training))
+    out = _bn(F.conv2d(out, sd[p + ".conv3.weight"]), sd, p + ".bn3", training)
+    if (p + ".downsample.0.weight") in sd:
+        x = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride), sd,
+                p + ".downsample.1", training)
+    return F.relu(out + x)
+
+
+def resnet50_layer3(x, sd, prefix="backbone.0.body", training=False):
+    """conv1/bn/relu/maxpool, layer1 (3), layer2 (4, stride 2), layer3 (6, stride 1;
+    first block dilation 2, the rest dilation 1 — resnet.py:112,152-167) -> [B,1024,H/8,W/8]."""
+    p = prefix
+    x = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], stride=2, padding=3), sd, p + ".bn1", training))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for name, nblk, stride, dil in (("layer1", 3, 1, 1), ("layer2", 4, 2, 1), ("layer3", 6, 1, 2)):
+        for b in range(nblk):
+            first = b == 0
+            x = _bottleneck(x, sd, "%s.%s.%d" % (p, name, b), stride if first else 1,
+                            dil if first else 1, training)
+    return x
+
+
+# --------------------------------------------------------------------------
+# attention and fusion (ltr/models/neck/transt_fusion.py)
+# --------------------------------------------------------------------------
+def mha(xq, pq, xk, pk, sd, p, nhead, key_padding_mask=None):
+    """nn.MultiheadAttention as called at transt_fusion.py:145-148,212-230.
+
+    q = (xq+pq) Wq^T + bq, k = (xk+pk) Wk^T + bk, v = xk Wv^T + bv (no pos on v);
+    q scaled by 1/sqrt(d_head) after the projection; key-padding mask -> -inf;
+    softmax over keys; out-projection.  Tensors are [B, L, C].
+    """
+    W, b = sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"]
+    C = W.shape[1]
+    dh = C // nhead
+    q = F.linear(xq + pq if pq is not None else xq, W[:C], b[:C])
+    k = F.linear(xk + pk if pk is not None else xk, W[C:2 * C], b[C:2 * C])
+    v = F.linear(xk, W[2 * C:], b[2 * C:])
+    B, Lq, _ = q.shape
+    Lk = k.shape[1]
+    q = q.view(B, Lq, nhead, dh).transpose(1, 2) * (1.0 / math.sqrt(dh))
+    k = k.view(B, Lk, nhead, dh).transpose(1, 2)
+    v = v.view(B, Lk, nhead, dh).transpose(1, 2)
+    s = q @ k.transpose(-1, -2)                                  # [B,h,Lq,Lk]
+    if key_padding_mask is not None:
+        s = s.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+    a = torch.softmax(s, dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(B, Lq, C)
+    return F.linear(o, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
+
+
+def _ln(x, sd, p):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+def _ffn(x, sd, p1, p2):
+    return F.linear(F.relu(F.linear(x, sd[p1 + ".weight"], sd[p1 + ".bias"])),
+                    sd[p2 + ".weight"], sd[p2 + ".bias"])
+
+
+def fusion_layer(s1, s2, p1, p2, m1, m2, sd, p, nhead):
+    """FeatureFusionLayer.forward_post (transt_fusion.py:204-244), dropout off."""
+    s1 = _ln(s1 + mha(s1, p1, s1, p1, sd, p + ".self_attn1", nhead, m1), sd, p + ".norm11")
+    s2 = _ln(s2 + mha(s2, p2, s2, p2, sd, p + ".self_attn2", nhead, m2), sd, p + ".norm21")
+    a12 = mha(s1, p1, s2, p2, sd, p + ".multihead_attn1", nhead, m2)
+    a22 = mha(s2, p2, s1, p1, sd, p + ".multihead_attn2", nhead, m1)
+    s1 = _ln(s1 + a12, sd, p + ".norm12")
+    s1 = _ln(s1 + _ffn(s1, sd, p + ".linear11", p + ".linear12"), sd, p + ".norm13")
+    s2 = _ln(s2 + a22, sd, p + ".norm22")
+    s2 = _ln(s2 + _ffn(s2, sd, p + ".linear21", p + ".linear22"), sd, p + ".norm23")
+    return s1, s2
+
+
+def decoder_layer(tgt, mem, pos_dec, pos_enc, mem_mask, sd, p, nhead):
+    """DecoderCFALayer.forward_post (transt_fusion.py:138-154)."""
+    tgt = _ln(tgt + mha(tgt, pos_dec, mem, pos_enc, sd, p + ".multihead_attn", nhead, mem_mask),
+              sd, p + ".norm1")
+    return _ln(tgt + _ffn(tgt, sd, p + ".linear1", p + ".linear2"), sd, p + ".norm2")
+
+
+def fusion_network(src_t, mask_t, src_s, mask_s, pos_t, pos_s, sd, prefix, nhead, nlayers):
+    """FeatureFusionNetwork.forward (transt_fusion.py:38-57).
+
+    Inputs NCHW ([B,C,H,W]) + masks [B,H,W]; output hs [1, B, Ls, C].
+    """
+    tok = lambda t: t.flatten(2).transpose(1, 2)          # [B, HW, C]
+    s1, s2, p1, p2 = tok(src_t), tok(src_s), tok(pos_t), tok(pos_s)
+    m1 = mask_t.flatten(1) if mask_t is not None else None
+    m2 = mask_s.flatten(1) if mask_s is not None else None
+    pre = prefix + "." if prefix else ""
+    for i in range(nlayers):
+        s1, s2 = fusion_layer(s1, s2, p1, p2, m1, m2, sd, "%sencoder.layers.%d" % (pre, i), nhead)
+    hs = decoder_layer(s2, s1, p2, p1, m1, sd, pre + "decoder.layers.0", nhead)
+    hs = _ln(hs, sd, pre + "decoder.norm")
+    return hs.unsqueeze(0)
+
+
+def mlp(x, sd, p, nlayers=3):
+    """MLP (transt_model.py:296-310)."""
+    for i in range(nlayers):
+        x = F.linear(x, sd["%s.layers.%d.weight" % (p, i)], sd["%s.layers.%d.bias" % (p, i)])
+        if i < nlayers - 1:
+            x = F.relu(x)
+    return x
+
+
+def transt_features(img, sd, training=False):
+    """Joiner + input_proj (transt_backbone.py:62-70,89-98; transt_model.py:270-275).
+
+    Full-size crops: the padding mask is all False (misc.py:283-300 with equal sizes).
+    """
+    f = resnet50_layer3(img, sd, "backbone.0.body", training)
+    B, _, H, W = f.shape
+    mask = torch.zeros(B, H, W, dtype=torch.bool)
+    pos = position_embedding_sine(mask, sd["input_proj.weight"].shape[0] // 2)
+    src = F.conv2d(f, sd["input_proj.weight"], sd["input_proj.bias"])
+    return src, mask, pos
+
+
+def transt_heads(hs, sd, b_iou=None):
+    """_fusion_pipeline heads (transt_model.py:73-84)."""
+    out = {"pred_logits": mlp(hs, sd, "class_embed")[-1],
+           "pred_boxes": mlp(hs, sd, "bbox_embed").sigmoid()[-1]}
+    if b_iou is not None and "iou_embed.layers.0.weight" in sd:
+        out["pred_ious"] = mlp(hs[:, :b_iou].detach(), sd, "iou_embed").sigmoid()[-1]
+    return out
+
+
+def transt_forward(template_u8, search_u8, sd, nhead=8, nlayers=4, b_iou=None, training=False,
+                   mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """TransT.forward for one (template, search) batch (transt_model.py:229-293), no augmentation."""
+    z, _ = preprocess(template_u8, torch.zeros(template_u8.shape[0], 3), mean, std)
+    x, _ = preprocess(search_u8, torch.zeros(search_u8.shape[0], 3), mean, std)
+    src_s, mask_s, pos_s = transt_features(x, sd, training)
+    src_t, mask_t, pos_t = transt_features(z, sd, training)
+    hs = fusion_network(src_t, mask_t, src_s, mask_s, pos_t, pos_s, sd, "featurefusion_network",
+                        nhead, nlayers)
+    return transt_heads(hs, sd, b_iou if b_iou is not None else search_u8.shape[0])
+
+
+# --------------------------------------------------------------------------
+# pseudo-label decode (ltr/actor/transt_sparse_actor.py:57-98)
+# --------------------------------------------------------------------------
+def hanning_window(feat_sz):
+    h = torch.tensor(np.hanning(feat_sz), dtype=torch.float32)
+    return torch.outer(h, h).flatten()
+
+
+def decode_teacher(pred_logits, pred_boxes, pred_ious, window_penalty, feat_sz, img_w, img_h):
+    """softmax[:, :, 0]; Hanning blend; arg-max token; gather box + IoU conf; cxcywh -> xywh px; clamp."""
+    score = torch.softmax(pred_logits, dim=2)[:, :, 0]
+    win = hanning_window(feat_sz)
+    s = window_penalty * win[None, :] + (1 - window_penalty) * score
+    best_score, best_idx = torch.max(s, dim=1)
+    ar = torch.arange(pred_boxes.shape[0])
+    bbox = pred_boxes[ar, best_idx].clone()
+    conf = pred_ious[ar, best_idx].reshape(-1)
+    out = torch.empty_like(bbox)
+    out[:, 0] = ((bbox[:, 0] - bbox[:, 2] / 2) * img_w).clamp_min(0)
+    out[:, 1] = ((bbox[:, 1] - bbox[:, 3] / 2) * img_h).clamp_min(0)
+    out[:, 2] = (bbox[:, 2] * img_w).clamp_min(1)
+    out[:, 3] = (bbox[:, 3] * img_h).clamp_min(1)
+    return {"best_bbox": out, "best_score": best_score, "best_conf": conf, "best_idx": best_idx,
+            "score_map": s}
+
+
+# --------------------------------------------------------------------------
+# middleware box transforms + filter
+# (ltr/data/processing_utils.py:180-229, ltr/data/middleware.py:97-152)
+# --------------------------------------------------------------------------
+def recover_bbox_to_original(box_crop, box_extract, resize_factor, crop_sz):
+    rf = resize_factor.reshape(-1, 1)
+    ext_c = box_extract[:, 0:2] + 0.5 * box_extract[:, 2:4]
+    crop_c = box_crop[:, 0:2] + 0.5 * box_crop[:, 2:4]
+    wh = box_crop[:, 2:4] / rf
+    c = (crop_c - (crop_sz - 1) / 2) / rf + ext_c
+    return torch.cat((c - 0.5 * wh, wh), dim=1).clamp(min=0.0)
+
+
+def transform_image_to_crop(box_in, box_extract, resize_factor, crop_sz):
+    rf = resize_factor.reshape(-1, 1)
+    ext_c = box_extract[:, 0:2] + 0.5 * box_extract[:, 2:4]
+    in_c = box_in[:, 0:2] + 0.5 * box_in[:, 2:4]
+    out_c = (crop_sz - 1) / 2 + (in_c - ext_c) * rf
+    wh = box_in[:, 2:4] * rf
+    return torch.cat((out_c - 0.5 * wh, wh), dim=1)
+
+
+def middleware_filter(best_bbox, best_conf, unl_box_extract, unl_rf, aug_box_extract, aug_rf,
+                      search_sz, tau):
+    """record_relay_results (middleware.py:49-95): recover, keep = conf >= tau, re-project, clamp >= 0."""
+    rec = recover_bbox_to_original(best_bbox, unl_box_extract.reshape(-1, 4), unl_rf, search_sz)
+    keep = best_conf >= tau
+    aug = transform_image_to_crop(rec, aug_box_extract.reshape(-1, 4), aug_rf, search_sz).clamp_min(0.0)
+    return {"aug_anno": aug, "aug_success": keep, "bbox_recovered": rec}
+
+
+# --------------------------------------------------------------------------
+# compaction / refill (ltr/trainers/ltr_sparse_trainer.py:334-357)
+# --------------------------------------------------------------------------
+def compact_indices(keep, batch):
+    """Rows kept in order, then refilled by repeatedly appending the first
+    min(missing, have) rows: a cyclic repetition of the kept indices."""
+    kept = [i for i in range(len(keep)) if bool(keep[i])]
+    if not kept:
+        return None                        # reference skips the iteration (:328-332)
+    idx = list(kept)
+    while len(idx) < batch:
+        n = min(batch - len(idx), len(idx))
+        idx = idx + idx[:n]
+    return np.asarray(idx, dtype=np.int64)
+
+
+# --------------------------------------------------------------------------
+# boxes (ltr/utils/box_ops.py:9-32,105-156)
+# --------------------------------------------------------------------------
+def box_cxcywh_to_xyxy(x):
+    cx, cy, w, h = x.unbind(-1)
+    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+
+def box_xyxy_to_xywh(x):
+    x0, y0, x1, y1 = x.unbind(-1)
+    return torch.stack([x0, y0, x1 - x0, y1 - y0], dim=-1)
+
+
+def box_xyxy_to_cxcywh(x):
+    x0, y0, x1, y1 = x.unbind(-1)
+    return torch.stack([(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0], dim=-1)
+
+
+def box_iou_pair_xyxy(b1, b2):
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    wh = (torch.min(b1[:, 2:], b2[:, 2:]) - torch.max(b1[:, :2], b2[:, :2])).clamp(min=0)
+    inter = wh[:, 0] * wh[:, 1]
+    union = a1 + a2 - inter
+    return inter / union, union
+
+
+def generalized_box_iou_pair_xyxy(b1, b2):
+    iou, union = box_iou_pair_xyxy(b1, b2)
+    wh = (torch.max(b1[:, 2:], b2[:, 2:]) - torch.min(b1[:, :2], b2[:, :2])).clamp(min=0)
+    area = wh[:, 0] * wh[:, 1]
+    return iou - (area - union) / area, iou
+
+
+# --------------------------------------------------------------------------
+# matcher + criterion (ltr/models/loss/transt_matcher.py:24-109,
+#                      ltr/models/tracking/transt_criterion.py:40-109,136-170)
+# --------------------------------------------------------------------------
+def matcher_masks(gt_cxcywh, num_queries, with_neg, gap=3):
+    """Positive-token mask [B,L] and negative-token multiplicity [B,L] (int).
+
+    The reference's negative ring is the union of four rectangles that do not
+    overlap, so multiplicities are 0/1; kept as counts to stay literal.
+    """
+    B = gt_cxcywh.shape[0]
+    n = int(np.sqrt(num_queries))
+    pos = np.zeros((B, n, n), bool)
+    neg = np.zeros((B, n, n), np.int32)
+    g = np.asarray(gt_cxcywh, dtype=np.float32)
+    for i in range(B):
+        cx, cy, w, h = (float(v) for v in g[i])
+        X0 = max(int(np.ceil((cx - w / 2) * n)), 0)
+        Y0 = max(int(np.ceil((cy - h / 2) * n)), 0)
+        X1 = min(int(np.ceil((cx + w / 2) * n)), n)
+        Y1 = min(int(np.ceil((cy + h / 2) * n)), n)
+        if X0 == X1:
+            X1 += 1
+        if Y0 == Y1:
+            Y1 += 1
+        pos[i, Y0:Y1, X0:X1] = True
+        if with_neg:
+            Yo0, Yo1, Xo0, Xo1 = max(0, Y0 - gap), min(n, Y1 + gap), max(0, X0 - gap), min(n, X1 + gap)
+            for (a, b, c, d) in ((Yo0, Yo1, Xo0, X0), (Yo0, Y0, X0, X1), (Y1, Yo1, X0, X1),
+                                 (Yo0, Yo1, X1, Xo1)):
+                neg[i, a:b, c:d] += 1
+    return pos.reshape(B, -1), neg.reshape(B, -1)
+
+
+def criterion(logits, boxes, ious, gt_cxcywh, eos_coef=0.0625, tag="sup"):
+    """SetCriterionTransT.forward for one tag; returns the reference's loss dict."""
+    B, L, _ = logits.shape
+    pos, neg = matcher_masks(gt_cxcywh.detach().numpy(), L, with_neg=(tag == "sup"))
+    pos_t = torch.from_numpy(pos)
+    target = torch.where(pos_t, torch.zeros((), dtype=torch.int64), torch.ones((), dtype=torch.int64))
+    w = torch.tensor([1.0, eos_coef])
+    losses = {"loss_ce": F.cross_entropy(logits.transpose(1, 2), target, w)}
+    num_pos = max(float(pos.sum()), 1.0)
+    bi, ti = torch.nonzero(pos_t, as_tuple=True)
+    src = boxes[bi, ti]
+    tgt = gt_cxcywh[bi]
+    giou, iou = generalized_box_iou_pair_xyxy(box_cxcywh_to_xyxy(src), box_cxcywh_to_xyxy(tgt))
+    losses["loss_bbox"] = (src - tgt).abs().sum() / num_pos
+    losses["loss_giou"] = (1 - giou).sum() / num_pos
+    losses["iou"] = iou.sum() / num_pos
+    if tag == "sup" and ious is not None:
+        num_neg = max(float(neg.sum()), 1.0)
+        l_pos = (ious.squeeze(2)[bi, ti] - iou.detach()).abs().sum() / num_pos
+        neg_t = torch.from_numpy(neg)
+        nb, nt = torch.nonzero(neg_t > 0, as_tuple=True)
+        mult = neg_t[nb, nt].float()
+        iou_n, _ = box_iou_pair_xyxy(box_cxcywh_to_xyxy(boxes[nb, nt]), box_cxcywh_to_xyxy(gt_cxcywh[nb]))
+        l_neg = ((ious.squeeze(2)[nb, nt] - iou_n.detach()).abs() * mult).sum() / num_neg
+        losses["loss_iou_pred"] = l_pos + l_neg
+    return losses
+
+
+def build_target(anno_xywh_px, w, h):
+    """_build_targets (transt_sparse_actor.py:203-224): xywh px -> normalised cxcywh."""
+    a = anno_xywh_px
+    return torch.stack([(a[:, 0] + a[:, 2] / 2) / w, (a[:, 1] + a[:, 3] / 2) / h, a[:, 2] / w, a[:, 3] / h], dim=1)
+
+
+def sp_training_loss(out_sup, out_unsup, search_anno, aug_anno, weight_dict, eos_coef=0.0625,
+                     search_hw=(256, 256)):
+    """_sp_training (transt_sparse_actor.py:140-201): two criterion calls, batch-weighted sum."""
+    h, w = search_hw
+    bs, bu = search_anno.shape[0], aug_anno.shape[0]
+    ls = criterion(out_sup["logits"], out_sup["boxes"], out_sup.get("ious"), build_target(search_anno, w, h),
+                   eos_coef, "sup")
+    lu = criterion(out_unsup["logits"], out_unsup["boxes"], None, build_target(aug_anno, w, h),
+                   eos_coef, "unsup")
+    loss_sup = sum(ls[k] * weight_dict[k + "_sup"] for k in ls if k + "_sup" in weight_dict)
+    loss_unsup = sum(lu[k] * weight_dict[k + "_unsup"] for k in lu if k + "_unsup" in weight_dict)
+    total = (float(bs) * loss_sup + float(bu) * loss_unsup) / (bs + bu)
+    return total, ls, lu
+
+
+# --------------------------------------------------------------------------
+# depthwise cross-correlation head (ltr/models/neck/ocean_fusion.py:211-247)
+# --------------------------------------------------------------------------
+def xcorr_depthwise(x, z):
+    """out[b,c,i,j] = sum_{u,v} x[b,c,i+u,j+v] * z[b,c,u,v] (valid correlation), numpy."""
+    x = np.asarray(x, dtype=np.float32)
+    z = np.asarray(z, dtype=np.float32)
+    B, C, Hx, Wx = x.shape
+    _, _, Hz, Wz = z.shape
+    Ho, Wo = Hx - Hz + 1, Wx - Wz + 1
+    out = np.zeros((B, C, Ho, Wo), np.float32)
+    for u in range(Hz):
+        for v in range(Wz):
+            out += x[:, :, u:u + Ho, v:v + Wo] * z[:, :, u:u + 1, v:v + 1]
+    return out
+
+
+def groupdw(xs, zs, weight):
+    """GroupDW.forward: sum_i softmax(weight)_i * xcorr(x_i, z_i)."""
+    w = np.asarray(weight, dtype=np.float32)
+    e = np.exp(w - w.max())
+    sw = (e / e.sum()).astype(np.float32)
+    s = 0
+    for i in range(3):
+        s = s + sw[i] * xcorr_depthwise(xs[i], zs[i])
+    return s.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# teacher EMA (ltr/actor/transt_sparse_actor.py:11-33)
+# --------------------------------------------------------------------------
+def ema_update(teacher_sd, student_sd, keep_rate):
+    """new = student*(1-keep) + teacher*keep for every entry; the result is cast
+    back to the teacher entry's dtype by load_state_dict (int64 buffers truncate)."""
+    out = {}
+    for k, v in teacher_sd.items():
+        new = student_sd[k] * (1 - keep_rate) + v * keep_rate
+        out[k] = new.to(v.dtype)
+    return out
+
+
+# --------------------------------------------------------------------------
+# online tracker post-processing (pysot_toolkit/trackers/transt_tracker.py:21-39,146-193)
+# --------------------------------------------------------------------------
+def tracker_post(pred_logits, pred_boxes, window, window_penalty, center_pos, size, image_hw):
+    """One track() step after the network: returns (bbox xywh, pscore, new center, new size, s_x)."""
+    w_x = size[0] + 3 * ((size[0] + size[1]) * 0.5)
+    h_x = size[1] + 3 * ((size[0] + size[1]) * 0.5)
+    s_x = math.ceil(math.sqrt(w_x * h_x))
+    lg = np.asarray(pred_logits, dtype=np.float32).reshape(-1, 2)
+    e = np.exp(lg - lg.max(axis=1, keepdims=True))
+    score = (e[:, 0] / e.sum(axis=1)).astype(np.float32)
+    delta = np.asarray(pred_boxes, dtype=np.float32).reshape(-1, 4).T
+    pscore = score * (1 - window_penalty) + window * window_penalty
+    best = int(np.argmax(pscore))
+    bbox = delta[:, best] * s_x
+    cx = bbox[0] + center_pos[0] - s_x / 2
+    cy = bbox[1] + center_pos[1] - s_x / 2
+    H, W = image_hw
+    cx = max(0, min(cx, W))
+    cy = max(0, min(cy, H))
+    width = max(10, min(bbox[2], W))
+    height = max(10, min(bbox[3], H))
+    return ([cx - width / 2, cy - height / 2, width, height], pscore,
+            np.array([cx, cy]), np.array([width, height]), s_x)

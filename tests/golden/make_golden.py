@@ -1,0 +1,674 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the reference.
+
+Runs ONLY in the build container, where the read-only reference checkout is
+mounted at /root/reference.  Nothing here travels to the GPU box except the
+.npz files it writes (data: seeded inputs' descriptors and expected outputs).
+
+How the reference is imported (all CPU, torch 2.x):
+  * `torchvision` is absent in this image.  The reference uses three trivial
+    helpers from it (box area, per-channel normalise, a version string); a
+    minimal stand-in module exposes exactly those.
+  * `cv2` is absent; it is only used by visualisation / CPU cropping code that
+    is never executed here.  An empty module object satisfies the import.
+  * `ltr/data/__init__.py` pulls in the DataLoader stack, which needs
+    `torch._six`, `jpeg4py`, `part`.  The two files on the hot path
+    (`processing_utils.py`, `middleware.py`) are loaded by file path instead.
+  * `tensorboard` is absent; `ltr.admin.tensorboard` (a logging writer the
+    trainer module imports, never called here) is replaced by an empty class.
+  * The Ocean modules need a compiled CUDA extension and cannot be imported;
+    the depthwise cross-correlation golden is produced by executing the same
+    ATen call the reference makes (grouped `F.conv2d`) on seeded inputs.
+  * Weights: seeded, from spot_amd.detinit (no checkpoints exist offline);
+    `backbone_pretrained=False` (the pretrained path is a network fetch).
+  * Everything runs in eval() with the MHA fast path disabled, jitter 0,
+    no stochastic augmentation, unless a case says otherwise.
+
+Usage:  python tests/golden/make_golden.py [case ...]
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+from spot_amd.detinit import det_fill_, det_input  # noqa: E402
+
+
+# --------------------------------------------------------------------------
+# import plumbing
+# --------------------------------------------------------------------------
+def _install_stubs():
+    tv = types.ModuleType("torchvision")
+    tv.__version__ = "0.9.1"
+    ops = types.ModuleType("torchvision.ops")
+    boxes = types.ModuleType("torchvision.ops.boxes")
+    boxes.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    misc = types.ModuleType("torchvision.ops.misc")
+    misc.interpolate = F.interpolate
+    ops.boxes, ops.misc = boxes, misc
+    models = types.ModuleType("torchvision.models")
+    resnet = types.ModuleType("torchvision.models.resnet")
+    resnet.model_urls = {}
+    models.resnet = resnet
+    tr = types.ModuleType("torchvision.transforms")
+    trf = types.ModuleType("torchvision.transforms.functional")
+
+    def normalize(t, mean, std, inplace=False):
+        m = torch.as_tensor(mean, dtype=t.dtype, device=t.device).view(-1, 1, 1)
+        s = torch.as_tensor(std, dtype=t.dtype, device=t.device).view(-1, 1, 1)
+        if inplace:
+            return t.sub_(m).div_(s)
+        return (t - m) / s
+
+    trf.normalize = normalize
+    tr.functional = trf
+    tv.ops, tv.models, tv.transforms = ops, models, tr
+    for name, mod in [("torchvision", tv), ("torchvision.ops", ops),
+                      ("torchvision.ops.boxes", boxes), ("torchvision.ops.misc", misc),
+                      ("torchvision.models", models), ("torchvision.models.resnet", resnet),
+                      ("torchvision.transforms", tr),
+                      ("torchvision.transforms.functional", trf)]:
+        sys.modules[name] = mod
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    # the trainer module imports a TensorBoard writer (package absent here);
+    # logging is not on the path under test
+    tb = types.ModuleType("ltr.admin.tensorboard")
+    tb.TensorboardWriter = type("TensorboardWriter", (), {"__init__": lambda self, *a, **k: None})
+    sys.modules["ltr.admin.tensorboard"] = tb
+    # ltr.data as a bare package (its __init__ needs the DataLoader stack)
+    sys.path.insert(0, REF)
+    import ltr  # noqa: F401  (namespace package)
+    data_pkg = types.ModuleType("ltr.data")
+    data_pkg.__path__ = [os.path.join(REF, "ltr", "data")]
+    sys.modules["ltr.data"] = data_pkg
+    for leaf in ("processing_utils", "middleware"):
+        spec = importlib.util.spec_from_file_location(
+            "ltr.data." + leaf, os.path.join(REF, "ltr", "data", leaf + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["ltr.data." + leaf] = mod
+        spec.loader.exec_module(mod)
+        setattr(data_pkg, leaf, mod)
+
+
+class Settings:
+    """Plain namespace with the attribute names of spot_transt_003.py:21-111."""
+
+    def __init__(self, **kw):
+        self.device = "cpu"
+        self.position_embedding = "sine"
+        self.hidden_dim = 256
+        self.dropout = 0.1
+        self.nheads = 8
+        self.dim_feedforward = 2048
+        self.featurefusion_layers = 4
+        self.num_classes = 1
+        self.eos_coef = 0.0625
+        self.weight_dict = {'loss_ce_sup': 8.334, 'loss_bbox_sup': 5, 'loss_giou_sup': 2,
+                            'loss_iou_pred_sup': 1.0, 'loss_ce_unsup': 8.334,
+                            'loss_bbox_unsup': 5, 'loss_giou_unsup': 2}
+        self.search_feature_sz = 32
+        self.template_feature_sz = 16
+        self.search_sz = 256
+        self.temp_sz = 128
+        self.normalize_mean = [0.485, 0.456, 0.406]
+        self.normalize_std = [0.229, 0.224, 0.225]
+        self.curriculum_settings = {'confidence_threshold': 0.85, 'max_gap': None,
+                                    'propagating_step': 1, 'window_penalty': 0.40}
+        self.iou_prediction_tag = True
+        self.printing_auxiliary_info = False
+        self.state_saving_interval = None
+        self.magic_number = "golden"
+        self.env = types.SimpleNamespace(var_dir="/tmp/spot_golden_var")
+        self.batch_size_sup = 8
+        self.batch_size_unsup = 24
+        self.batch_size = 32
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def t2n(t):
+    return t.detach().cpu().numpy().copy()
+
+
+# --------------------------------------------------------------------------
+# builders
+# --------------------------------------------------------------------------
+def build_transt(settings, seed, dropout=None):
+    from ltr.models.backbone.transt_backbone import build_backbone
+    from ltr.models.neck.transt_fusion import build_featurefusion_network
+    from ltr.models.pre_input import NecessaryPreprocess
+    from ltr.models.tracking.transt_model import TransT
+    if dropout is not None:
+        settings.dropout = dropout
+    backbone = build_backbone(settings, backbone_pretrained=False)
+    fusion = build_featurefusion_network(settings)
+    pre = NecessaryPreprocess(b_j=0.0, mean=settings.normalize_mean, std=settings.normalize_std)
+    net = TransT(backbone, fusion, num_classes=1, iou_prediction=True,
+                 necessary_pre=pre, joint_trans=None, independent_trans=None)
+    det_fill_(net, seed)
+    return net
+
+
+def teacher_inputs(B, seed):
+    """Synthetic clip batch in the layout of the reference's unsup loader."""
+    d = {}
+    d["key_images"] = det_input("key_images", (B, 3, 128, 128), seed, 0, 256, np.uint8)
+    d["unlabeled_images"] = det_input("unlabeled_images", (B, 3, 256, 256), seed, 0, 256, np.uint8)
+    d["key_avg"] = det_input("key_avg", (B, 3), seed, 0, 255)
+    d["unlabeled_avg"] = det_input("unlabeled_avg", (B, 3), seed, 0, 255)
+    d["key_anno"] = det_input("key_anno", (B, 4), seed, 20, 80)
+    d["unlabeled_anno"] = det_input("unlabeled_anno", (B, 4), seed, 40, 120)
+    return d
+
+
+def middle_inputs(B, seed):
+    m = {}
+    xy = det_input("unl_xy", (B, 1, 2), seed, 0, 400)
+    wh = det_input("unl_wh", (B, 1, 2), seed, 20, 200)
+    m["unlabeled_box_extract"] = np.concatenate([xy, wh], -1).astype(np.float32)
+    m["unlabeled_resize_factors"] = det_input("unl_rf", (B,), seed, 0.5, 2.0)
+    xy = det_input("aug_xy", (B, 1, 2), seed, 0, 400)
+    wh = det_input("aug_wh", (B, 1, 2), seed, 20, 200)
+    m["aug_box_extract"] = np.concatenate([xy, wh], -1).astype(np.float32)
+    m["aug_resize_factors"] = det_input("aug_rf", (B,), seed, 0.5, 2.0)
+    return m
+
+
+def run_middleware(settings, middle, pseudo):
+    from ltr.data.middleware import SparseMiddleware
+    mw = SparseMiddleware(settings)
+    B = pseudo["best_bbox"].shape[0]
+    mi = {k: torch.from_numpy(np.asarray(v)) for k, v in middle.items()}
+    mi["key_record_keys"] = [[("seq%d" % i, 0, 0)] for i in range(B)]
+    mi["unlabeled_record_keys"] = [[("seq%d" % i, 0, 1)] for i in range(B)]
+    return mw.record_relay_results(mi, pseudo)
+
+
+# --------------------------------------------------------------------------
+# cases
+# --------------------------------------------------------------------------
+def case_fusion():
+    """G1/G2: FeatureFusionNetwork forward, tiny (full hs) and full size (slices)."""
+    from ltr.models.neck.transt_fusion import FeatureFusionNetwork
+    # tiny, with a key-padding mask on sample 1
+    d, nh, nl, ff, B, ht, hs_ = 64, 2, 2, 128, 2, 4, 8
+    net = det_fill_(FeatureFusionNetwork(d, nh, nl, ff, 0.1), seed=11).eval()
+    st = det_input("src_temp", (B, d, ht, ht), 11, -1, 1)
+    ss = det_input("src_search", (B, d, hs_, hs_), 11, -1, 1)
+    pt = det_input("pos_temp", (B, d, ht, ht), 11, -1, 1)
+    ps = det_input("pos_search", (B, d, hs_, hs_), 11, -1, 1)
+    mt = np.zeros((B, ht, ht), bool)
+    ms = np.zeros((B, hs_, hs_), bool)
+    mt[1, :, 3:] = True
+    ms[1, 6:, :] = True
+    with torch.no_grad():
+        out = net(torch.from_numpy(st), torch.from_numpy(mt), torch.from_numpy(ss),
+                  torch.from_numpy(ms), torch.from_numpy(pt), torch.from_numpy(ps))
+    save("g1_fusion_tiny", seed=11, dims=[d, nh, nl, ff, B, ht, hs_], mask_temp=mt,
+         mask_search=ms, hs=t2n(out))
+    # full size
+    d, nh, nl, ff, B, ht, hs_ = 256, 8, 4, 2048, 2, 16, 32
+    net = det_fill_(FeatureFusionNetwork(d, nh, nl, ff, 0.1), seed=12).eval()
+    st = det_input("src_temp", (B, d, ht, ht), 12, -1, 1)
+    ss = det_input("src_search", (B, d, hs_, hs_), 12, -1, 1)
+    pt = det_input("pos_temp", (B, d, ht, ht), 12, -1, 1)
+    ps = det_input("pos_search", (B, d, hs_, hs_), 12, -1, 1)
+    z = lambda *s: torch.zeros(*s, dtype=torch.bool)
+    with torch.no_grad():
+        out = net(torch.from_numpy(st), z(B, ht, ht), torch.from_numpy(ss), z(B, hs_, hs_),
+                  torch.from_numpy(pt), torch.from_numpy(ps))
+    o = t2n(out)  # [1,B,1024,256]
+    save("g2_fusion_full", seed=12, dims=[d, nh, nl, ff, B, ht, hs_],
+         hs_slice=o[:, :, ::16, ::8], hs_rownorm=np.linalg.norm(o, axis=-1),
+         hs_first=o[0, 0, :4, :])
+
+
+def case_mha():
+    """G3: nn.MultiheadAttention as the fusion layers call it (pos on q/k, not v)."""
+    out = {}
+    for tag, (Lq, Lk) in {"tt": (256, 256), "ss": (1024, 1024), "ts": (256, 1024),
+                          "st": (1024, 256)}.items():
+        B, d, nh = 2, 256, 8
+        mha = det_fill_(torch.nn.MultiheadAttention(d, nh, dropout=0.1), seed=13).eval()
+        xq = det_input("xq" + tag, (Lq, B, d), 13, -1, 1)
+        pq = det_input("pq" + tag, (Lq, B, d), 13, -1, 1)
+        if Lq == Lk and tag in ("tt", "ss"):
+            xk, pk = xq, pq
+        else:
+            xk = det_input("xk" + tag, (Lk, B, d), 13, -1, 1)
+            pk = det_input("pk" + tag, (Lk, B, d), 13, -1, 1)
+        kpm = np.zeros((B, Lk), bool)
+        kpm[1, Lk - Lk // 8:] = True
+        kpm[1, 5] = True
+        with torch.no_grad():
+            o = mha(torch.from_numpy(xq + pq), torch.from_numpy(xk + pk),
+                    value=torch.from_numpy(xk), key_padding_mask=torch.from_numpy(kpm))[0]
+        o = t2n(o)
+        out["out_" + tag] = o[::8]          # every 8th query row, all batch, all channels
+        out["kpm_" + tag] = kpm
+        out["rownorm_" + tag] = np.linalg.norm(o, axis=-1)
+    save("g3_mha", seed=13, **out)
+
+
+def case_layer_bwd():
+    """G4: FeatureFusionLayer forward + backward at tiny size, dropout 0."""
+    from ltr.models.neck.transt_fusion import FeatureFusionLayer
+    d, nh, ff, B, Lt, Ls = 64, 2, 128, 2, 16, 64
+    layer = det_fill_(FeatureFusionLayer(d, nh, ff, 0.0), seed=14).train()
+    s1 = torch.from_numpy(det_input("s1", (Lt, B, d), 14, -1, 1)).requires_grad_()
+    s2 = torch.from_numpy(det_input("s2", (Ls, B, d), 14, -1, 1)).requires_grad_()
+    p1 = torch.from_numpy(det_input("p1", (Lt, B, d), 14, -1, 1))
+    p2 = torch.from_numpy(det_input("p2", (Ls, B, d), 14, -1, 1))
+    g1 = torch.from_numpy(det_input("g1", (Lt, B, d), 14, -1, 1))
+    g2 = torch.from_numpy(det_input("g2", (Ls, B, d), 14, -1, 1))
+    o1, o2 = layer(s1, s2, pos_src1=p1, pos_src2=p2)
+    ((o1 * g1).sum() + (o2 * g2).sum()).backward()
+    grads = {"grad." + k: t2n(p.grad) for k, p in layer.named_parameters()}
+    save("g4_layer_bwd", seed=14, dims=[d, nh, ff, B, Lt, Ls], out1=t2n(o1), out2=t2n(o2),
+         ds1=t2n(s1.grad), ds2=t2n(s2.grad), **grads)
+
+
+def case_teacher(B=8, seed=1):
+    """G5: teacher forward -> decode -> middleware filter (cfg-2 shapes, eval mode)."""
+    import ltr.actor as actors
+    from ltr.utils import TensorDict
+    S = Settings()
+    net = build_transt(S, seed=seed).eval()
+    # move the IoU head's output so confidences straddle tau = 0.85
+    actor = actors.TranstSparseActor(settings=S, student_net=net, teacher_net=net, objective=None)
+    d = teacher_inputs(B, seed)
+    with torch.no_grad():
+        data = TensorDict({k: torch.from_numpy(v.copy()) for k, v in d.items()})
+        data["masks"] = torch.zeros(B, dtype=torch.bool)
+        raw = net(teacher_data=data)
+        # calibrate: shift iou head bias so the median best-token confidence is ~tau
+        pseudo0 = actor._decode_teacher_result(data, {k: v.clone() for k, v in raw.items()})
+        conf = pseudo0["best_conf"]
+        logit = torch.log(conf / (1 - conf))
+        # tau lands in the middle of the gap between the two central samples
+        shift = float(np.log(0.85 / 0.15) - np.median(t2n(logit).astype(np.float64)))
+    det_shift = np.float32(shift)
+    with torch.no_grad():
+        net.iou_embed.layers[2].bias += det_shift
+        data = TensorDict({k: torch.from_numpy(v.copy()) for k, v in d.items()})
+        data["masks"] = torch.zeros(B, dtype=torch.bool)
+        raw = net(teacher_data=data)
+        raw = {k: v.clone() for k, v in raw.items()}
+        pseudo = actor._decode_teacher_result(data, {k: v.clone() for k, v in raw.items()})
+    gap = float((pseudo["best_conf"] - 0.85).abs().min())
+    assert gap > 1e-3, "golden ill-conditioned: a confidence sits %g from tau" % gap
+    mid = middle_inputs(B, seed)
+    res = run_middleware(S, mid, pseudo)
+    save("g5_teacher", seed=seed, B=B, iou_bias_shift=det_shift,
+         pred_logits=t2n(raw["pred_logits"]), pred_boxes=t2n(raw["pred_boxes"]),
+         pred_ious=t2n(raw["pred_ious"]),
+         best_bbox=t2n(pseudo["best_bbox"]), best_score=t2n(pseudo["best_score"]),
+         best_conf=t2n(pseudo["best_conf"]),
+         aug_anno=t2n(res["aug_anno"]), aug_success=t2n(res["aug_success"]))
+
+
+def case_decode():
+    """G6: decode-only and middleware-only on handcrafted network outputs."""
+    import ltr.actor as actors
+    S = Settings()
+    actor = actors.TranstSparseActor(settings=S, student_net=None, teacher_net=None, objective=None)
+    B, L = 16, 1024
+    logits = det_input("logits", (B, L, 2), 21, -4, 4)
+    boxes = det_input("boxes", (B, L, 4), 21, 0.02, 0.98)
+    ious = det_input("ious", (B, L, 1), 21, 0.0, 1.0)
+    # a few hand-placed winners: corner tokens, tiny boxes (clamp w,h>=1), boxes leaving the crop
+    logits[0, 0] = [9, -9]; boxes[0, 0] = [0.01, 0.01, 0.2, 0.2]
+    logits[1, 1023] = [9, -9]; boxes[1, 1023] = [0.99, 0.99, 0.001, 0.002]
+    logits[2, 528] = [12, -12]; boxes[2, 528] = [0.5, 0.5, 1.0, 1.0]
+    tau = np.float32(0.85)
+    eps = np.float32(np.spacing(tau))
+    best_conf_forced = [tau - eps, tau, tau + eps]
+    data = {"unlabeled_images": torch.zeros(B, 3, 256, 256)}
+    out = {"pred_logits": torch.from_numpy(logits), "pred_boxes": torch.from_numpy(boxes),
+           "pred_ious": torch.from_numpy(ious)}
+    with torch.no_grad():
+        pseudo = actor._decode_teacher_result(data, {k: v.clone() for k, v in out.items()})
+        # force the confidences of samples 3..5 onto tau-eps, tau, tau+eps
+        for j, c in enumerate(best_conf_forced):
+            pseudo["best_conf"][3 + j] = float(c)
+    mid = middle_inputs(B, 21)
+    res = run_middleware(S, mid, pseudo)
+    save("g6_decode", seed=21, logits=logits, boxes=boxes, ious=ious,
+         best_bbox=t2n(pseudo["best_bbox"]), best_score=t2n(pseudo["best_score"]),
+         best_conf=t2n(pseudo["best_conf"]), aug_anno=t2n(res["aug_anno"]),
+         aug_success=t2n(res["aug_success"]), **{"mid_" + k: v for k, v in mid.items()})
+
+
+def case_compaction():
+    """G7: the keep/refill rule of LTRSparseTrainer._sparse_training on index-valued data."""
+    from ltr.utils import TensorDict
+    try:
+        from ltr.trainers.ltr_sparse_trainer import LTRSparseTrainer
+    except Exception as e:  # tensorboard etc. absent
+        print("trainer import failed (%r); compaction golden skipped" % (e,))
+        return
+    B = 24
+    masks = {
+        "all": np.ones(B, bool), "one": np.eye(1, B, 7, dtype=bool)[0],
+        "first": np.eye(1, B, 0, dtype=bool)[0], "half": (np.arange(B) % 2 == 1),
+        "rand": det_input("keep", (B,), 31, 0, 1) > 0.6,
+        "five": np.isin(np.arange(B), [2, 3, 11, 17, 23]),
+        "most": ~np.isin(np.arange(B), [0, 5]),
+    }
+    out = {}
+
+    class Rec:
+        def train(self, mode=True):
+            pass
+
+        def __call__(self, mode, burnin_data=None, sp_data=None):
+            self.sp = sp_data
+            return torch.zeros(()), {}
+
+    for name, m in masks.items():
+        rec = Rec()
+        fake = types.SimpleNamespace(
+            actor=rec, move_data_to_gpu=False, device="cpu",
+            settings=types.SimpleNamespace(batch_size_sup=8, batch_size_unsup=B))
+        data_unsup = TensorDict()
+        for pre in ["relay", "aug"]:
+            for suf in ["images", "anno", "avg"]:
+                data_unsup["%s_%s" % (pre, suf)] = torch.arange(B, dtype=torch.float32).view(B, 1).clone()
+        aug = {"aug_anno": torch.arange(B, dtype=torch.float32).view(B, 1).clone(),
+               "aug_success": torch.from_numpy(m)}
+        torch.set_grad_enabled(False)
+        LTRSparseTrainer._sparse_training(fake, TensorDict(), data_unsup, aug, training=False)
+        out["mask_" + name] = m
+        out["idx_" + name] = t2n(rec.sp["relay_images"]).reshape(-1).astype(np.int64)
+    torch.set_grad_enabled(True)
+    save("g7_compaction", **out)
+
+
+def case_boxes():
+    """G8: paired IoU / GIoU and the box format conversions."""
+    from ltr.utils import box_ops
+    P = 64
+    c = det_input("c", (2, P, 2), 41, 0.2, 0.8)
+    wh = det_input("wh", (2, P, 2), 41, 0.02, 0.5)
+    b1 = np.concatenate([c[0], wh[0]], -1).astype(np.float32)
+    b2 = np.concatenate([c[1], wh[1]], -1).astype(np.float32)
+    b2[0] = b1[0]                                   # identical
+    b2[1] = [b1[1, 0], b1[1, 1], b1[1, 2] / 2, b1[1, 3] / 2]   # nested
+    b1[2] = [0.1, 0.1, 0.1, 0.1]; b2[2] = [0.8, 0.8, 0.1, 0.1]  # disjoint
+    b1[3] = [0.2, 0.2, 0.2, 0.2]; b2[3] = [0.4, 0.2, 0.2, 0.2]  # touching edge
+    t1, t2 = torch.from_numpy(b1), torch.from_numpy(b2)
+    x1, x2 = box_ops.box_cxcywh_to_xyxy(t1), box_ops.box_cxcywh_to_xyxy(t2)
+    giou, iou = box_ops.generalized_box_iou_pair_xyxy(x1, x2)
+    iou2, union = box_ops.box_iou_pair_xyxy(x1, x2)
+    # gradients of sum(1 - giou) wrt the first box set (as in the box loss)
+    t1g = t1.clone().requires_grad_()
+    g, _ = box_ops.generalized_box_iou_pair_xyxy(box_ops.box_cxcywh_to_xyxy(t1g), x2)
+    (1 - g).sum().backward()
+    save("g8_boxes", b1=b1, b2=b2, xyxy1=t2n(x1), giou=t2n(giou), iou=t2n(iou), iou2=t2n(iou2),
+         union=t2n(union), xywh1=t2n(box_ops.box_xyxy_to_xywh(x1)),
+         cxcywh1=t2n(box_ops.box_xyxy_to_cxcywh(x1)), dgiou_db1=t2n(t1g.grad))
+
+
+def _targets_from(boxes):
+    return [{"boxes": torch.from_numpy(b.reshape(1, 4).copy()), "labels": torch.tensor([0])}
+            for b in boxes]
+
+
+def case_matcher_criterion():
+    """G9/G10: matcher index sets at borders and criterion scalars + gradients."""
+    from ltr.models.loss.transt_matcher import TrackingMatcher
+    from ltr.models.tracking.transt_criterion import SetCriterionTransT
+    S = Settings()
+    B, L = 8, 1024
+    gt = np.array([[0.5, 0.5, 0.25, 0.25], [0.02, 0.03, 0.10, 0.12], [0.97, 0.98, 0.2, 0.1],
+                   [0.5, 0.5, 1.2, 1.2], [0.3, 0.7, 0.001, 0.001], [0.51, 0.49, 0.03125, 0.0625],
+                   [0.25, 0.25, 0.5, 0.5], [0.8, 0.2, 0.33, 0.61]], np.float32)
+    logits = det_input("logits", (B, L, 2), 51, -2, 2)
+    boxes = det_input("boxes", (B, L, 4), 51, 0.05, 0.6)
+    ious = det_input("ious", (B, L, 1), 51, 0.0, 1.0)
+    m = TrackingMatcher()
+    crit = SetCriterionTransT(S, m)
+    out = {}
+    for tag in ("sup", "unsup"):
+        o = {"logits_" + tag: torch.from_numpy(logits.copy()).requires_grad_(),
+             "boxes_" + tag: torch.from_numpy(boxes.copy()).requires_grad_()}
+        if tag == "sup":
+            o["ious_" + tag] = torch.from_numpy(ious.copy()).requires_grad_()
+        ind, ind_neg = m(o, _targets_from(gt), tag=tag)
+        pos_mask = np.zeros((B, L), bool)
+        neg_cnt = np.zeros((B, L), np.int32)
+        for i, (src, _) in enumerate(ind):
+            pos_mask[i, src.numpy()] = True
+        if ind_neg is not None:
+            for i, (src, _) in enumerate(ind_neg):
+                np.add.at(neg_cnt[i], src.numpy(), 1)
+        out["pos_mask_" + tag] = pos_mask
+        out["neg_count_" + tag] = neg_cnt
+        losses = crit(o, _targets_from(gt), tag=tag)
+        wd = S.weight_dict
+        total = sum(losses[k] * wd[k + "_" + tag] for k in losses if k + "_" + tag in wd)
+        total.backward()
+        for k, v in losses.items():
+            out["%s_%s" % (k, tag)] = t2n(v)
+        out["total_" + tag] = t2n(total)
+        for k, v in o.items():
+            out["grad_" + k] = t2n(v.grad)
+    save("g9_matcher_criterion", seed=51, gt=gt, **out)
+
+
+def case_tracker_post():
+    """G11: TransT_Tracker post-processing (transt_tracker.py:164-192) on fixed net outputs."""
+    spec = importlib.util.spec_from_file_location(
+        "ref_transt_tracker", os.path.join(REF, "pysot_toolkit", "trackers", "transt_tracker.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    N = 6
+    logits = det_input("trk_logits", (N, 1, 1024, 2), 61, -3, 3)
+    boxes = det_input("trk_boxes", (N, 1, 1024, 4), 61, 0.1, 0.9)
+
+    class Net:
+        def initialize(self):
+            pass
+
+        def template(self, z):
+            pass
+
+        def track(self, x):
+            i = self.i
+            return {"pred_logits": torch.from_numpy(logits[i]), "pred_boxes": torch.from_numpy(boxes[i])}
+
+    net = Net()
+    trk = mod.TransT_Tracker("g", net, window_penalty=0.49, exemplar_size=128, instance_size=256)
+    img = np.zeros((300, 400, 3), np.uint8)
+    trk.get_subwindow = lambda im, pos, msz, osz, avg: torch.zeros(1, 3, msz, msz)
+    trk.initialize(img, {"init_bbox": [150.0, 100.0, 60.0, 40.0]})
+    res_bbox, res_best, centers, sizes = [], [], [], []
+    for i in range(N):
+        net.i = i
+        o = trk.track(img)
+        res_bbox.append(o["target_bbox"])
+        res_best.append(float(np.max(o["best_score"])))
+        centers.append(trk.center_pos.copy())
+        sizes.append(trk.size.copy())
+    save("g11_tracker_post", seed=61, logits=logits, boxes=boxes, init_bbox=[150.0, 100.0, 60.0, 40.0],
+         image_hw=[300, 400], target_bbox=np.array(res_bbox), best=np.array(res_best),
+         center=np.array(centers), size=np.array(sizes))
+
+
+def case_xcorr():
+    """G12: depthwise cross-correlation and the 3-branch weighted sum.
+
+    ocean_fusion.py:238-247 reshapes x to [1, B*C, H, W], the kernel to
+    [B*C, 1, h, w] and calls F.conv2d with groups = B*C; ocean_fusion.py:220-235
+    combines three such maps with softmax(weight).  Executed here with ATen.
+    """
+    def xc(x, k):
+        b, c = k.shape[:2]
+        o = F.conv2d(x.reshape(1, b * c, *x.shape[2:]), k.reshape(b * c, 1, *k.shape[2:]), groups=b * c)
+        return o.reshape(b, c, *o.shape[2:])
+
+    out = {}
+    for tag, (hx, hz, C) in {"ocean255": (31, 7, 8), "cfg5": (47, 7, 4)}.items():
+        B = 2
+        shp_x = [(hx - 2, hx - 2), (hx - 4, hx - 2), (hx - 2, hx - 4)]
+        shp_z = [(hz - 2, hz - 2), (hz - 4, hz - 2), (hz - 2, hz - 4)]
+        xs = [torch.from_numpy(det_input("x%d%s" % (i, tag), (B, C) + s, 71, -1, 1)).requires_grad_()
+              for i, s in enumerate(shp_x)]
+        zs = [torch.from_numpy(det_input("z%d%s" % (i, tag), (B, C) + s, 71, -1, 1)).requires_grad_()
+              for i, s in enumerate(shp_z)]
+        w = torch.tensor([0.3, -0.2, 0.5], requires_grad=True)
+        re = [xc(x, z) for x, z in zip(xs, zs)]
+        sw = F.softmax(w, 0)
+        s = 0
+        for i in range(3):
+            s = s + sw[i] * re[i]
+        g = torch.from_numpy(det_input("g" + tag, tuple(s.shape), 71, -1, 1))
+        (s * g).sum().backward()
+        out["dims_" + tag] = [B, C, hx, hz]
+        out["re11_" + tag] = t2n(re[0])
+        out["groupdw_" + tag] = t2n(s)
+        out["dw_" + tag] = t2n(w.grad)
+        for i in range(3):
+            out["dx%d_%s" % (i, tag)] = t2n(xs[i].grad)
+            out["dz%d_%s" % (i, tag)] = t2n(zs[i].grad)
+    save("g12_xcorr", seed=71, weight=[0.3, -0.2, 0.5], **out)
+
+
+def case_ema():
+    """G13: teacher EMA update over a state dict incl. an int64 buffer."""
+    import ltr.actor as actors
+
+    def mk(seed):
+        m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Linear(8, 4))
+        det_fill_(m, seed)
+        m[1].num_batches_tracked.fill_(7 if seed == 81 else 100)
+        return m
+
+    stu, tea = mk(81), mk(82)
+    before = {k: t2n(v).copy() for k, v in tea.state_dict().items()}
+    actor = actors.TranstSparseActor(settings=None, student_net=stu, teacher_net=tea, objective=None)
+    actor._update_teacher_model(keep_rate=0.998)
+    after = {"after." + k: t2n(v) for k, v in tea.state_dict().items()}
+    actor._update_teacher_model(keep_rate=0)
+    copied = {"copied." + k: t2n(v) for k, v in tea.state_dict().items()}
+    save("g13_ema", keep_rate=0.998, **after, **copied)
+    del before
+
+
+def case_preprocess_posenc():
+    """G14: NecessaryPreprocess (jitter 0) and PositionEmbeddingSine."""
+    from ltr.models.pre_input import NecessaryPreprocess
+    from ltr.models.neck.position_encoding import PositionEmbeddingSine
+    from ltr.utils.misc import NestedTensor
+    S = Settings()
+    pre = NecessaryPreprocess(b_j=0.0, mean=S.normalize_mean, std=S.normalize_std)
+    img = det_input("img", (2, 3, 16, 16), 91, 0, 256, np.uint8)
+    avg = det_input("avg", (2, 3), 91, 0, 255)
+    o, a = pre({"t_images": torch.from_numpy(img), "t_avg": torch.from_numpy(avg.copy())}, tag="t")
+    pe = PositionEmbeddingSine(128, normalize=True)
+    out = {}
+    for hw in (16, 32):
+        m = torch.zeros(1, hw, hw, dtype=torch.bool)
+        out["pos%d" % hw] = t2n(pe(NestedTensor(torch.zeros(1, 1, hw, hw), m)))
+    m = torch.zeros(1, 8, 8, dtype=torch.bool)
+    m[0, :, 6:] = True
+    m[0, 7:, :] = True
+    out["pos8_masked"] = t2n(pe(NestedTensor(torch.zeros(1, 1, 8, 8), m)))
+    save("g14_pre_pos", seed=91, img_out=t2n(o), avg_out=t2n(a), mask8=t2n(m), **out)
+
+
+def case_student(seed=3):
+    """G15: student forward + losses + selected gradients (train mode, dropout 0, no aug).
+
+    BatchNorm runs in batch-statistics mode exactly as in the reference's
+    training step; dropout is 0 and the stochastic augmentations are off so
+    the result is deterministic.
+    """
+    import ltr.actor as actors
+    from ltr.models.tracking.transt_criterion import transt_loss
+    from ltr.utils import TensorDict
+    S = Settings()
+    net = build_transt(S, seed=seed, dropout=0.0).train()
+    crit = transt_loss(S)
+    actor = actors.TranstSparseActor(settings=S, student_net=net, teacher_net=net, objective=crit)
+    bs, bu = 2, 2
+
+    def mk(prefix_t, prefix_s, n, sd):
+        d = TensorDict()
+        d[prefix_t + "_images"] = torch.from_numpy(det_input(prefix_t + "_img", (n, 3, 128, 128), sd, 0, 256, np.uint8))
+        d[prefix_s + "_images"] = torch.from_numpy(det_input(prefix_s + "_img", (n, 3, 256, 256), sd, 0, 256, np.uint8))
+        d[prefix_t + "_avg"] = torch.from_numpy(det_input(prefix_t + "_avg", (n, 3), sd, 0, 255))
+        d[prefix_s + "_avg"] = torch.from_numpy(det_input(prefix_s + "_avg", (n, 3), sd, 0, 255))
+        d[prefix_t + "_anno"] = torch.from_numpy(det_input(prefix_t + "_anno", (n, 4), sd, 20, 60))
+        xy = det_input(prefix_s + "_xy", (n, 2), sd, 30, 120)
+        wh = det_input(prefix_s + "_wh", (n, 2), sd, 30, 100)
+        d[prefix_s + "_anno"] = torch.from_numpy(np.concatenate([xy, wh], -1).astype(np.float32))
+        return d
+
+    sup = mk("template", "search", bs, seed)
+    sp = mk("relay", "aug", bu, seed + 100)
+    sup["masks"] = torch.zeros(bs, dtype=torch.bool)
+    sp["masks"] = torch.ones(bu, dtype=torch.bool)
+    search_anno = t2n(sup["search_anno"]).copy()
+    aug_anno = t2n(sp["aug_anno"]).copy()
+    # TransT._refresh_anno only returns aug_anno when a transform is configured
+    # (transt_model.py:223); the reference always trains with joint_trans set.
+    from ltr.models.pre_input import JointTransform, GrayScale
+    net.joint_trans = JointTransform([GrayScale(gray_probability=0.0)])
+    loss, stats = actor(mode="spsup", burnin_data=sup, sp_data=sp)
+    loss.backward()
+    sd = dict(net.named_parameters())
+    pick = ["class_embed.layers.2.weight", "bbox_embed.layers.0.bias", "iou_embed.layers.2.weight",
+            "input_proj.weight", "featurefusion_network.decoder.layers.0.linear2.weight",
+            "featurefusion_network.encoder.layers.0.self_attn2.in_proj_weight",
+            "featurefusion_network.encoder.layers.3.norm13.weight",
+            "backbone.0.body.layer3.5.conv3.weight", "backbone.0.body.conv1.weight"]
+    out = {}
+    for k in pick:
+        g = t2n(sd[k].grad)
+        out["gnorm." + k] = np.linalg.norm(g)
+        out["gslice." + k] = g.reshape(-1)[:64]
+    allnorm = {k: float(np.linalg.norm(t2n(p.grad))) for k, p in sd.items() if p.grad is not None}
+    save("g15_student", seed=seed, bs=bs, bu=bu, loss=t2n(loss), search_anno=search_anno,
+         aug_anno=aug_anno, stat_keys=list(stats.keys()), stat_vals=[stats[k] for k in stats],
+         gn_keys=list(allnorm.keys()), gn_vals=list(allnorm.values()), **out)
+
+
+CASES = {
+    "fusion": case_fusion, "mha": case_mha, "layer_bwd": case_layer_bwd, "teacher": case_teacher,
+    "decode": case_decode, "compaction": case_compaction, "boxes": case_boxes,
+    "matcher_criterion": case_matcher_criterion, "tracker_post": case_tracker_post,
+    "xcorr": case_xcorr, "ema": case_ema, "pre_pos": case_preprocess_posenc,
+    "student": case_student,
+}
+
+
+def main(argv):
+    assert os.path.isdir(REF), "reference checkout not mounted; goldens can only be made in the build container"
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    torch.backends.mha.set_fastpath_enabled(False)
+    _install_stubs()
+    names = argv or list(CASES)
+    for n in names:
+        print("== case", n)
+        CASES[n]()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
