@@ -1,0 +1,191 @@
+/*
+ * spot_hip.h - C ABI of the MI355X (gfx950) library for SPOT's tracker hot path.
+ *
+ * Conventions
+ *   - Every entry point returns 0 on success or a negative code; the reason is
+ *     available from spot_last_error() (thread-local text).  No C++ exception
+ *     crosses this boundary.
+ *   - All data pointers are DEVICE pointers unless a parameter says "host".
+ *     The caller owns every buffer; nothing is retained past the call.
+ *   - Work is enqueued on `stream` and not synchronised.
+ *   - Token tensors are batch-first, row-major: [B, L, C].
+ *
+ * Each declaration cites the reference code it replaces (paths relative to the
+ * VISION-SJTU/SPOT checkout).  The reference has no FFI for this path: its seam
+ * is Python (torch.autograd.Function over compiled ops is its one precedent,
+ * ltr/models/neck/dcn/deform_conv.py:12-94), so these are the functions a
+ * ctypes binding in those Python modules calls.
+ */
+#ifndef SPOT_HIP_H
+#define SPOT_HIP_H
+
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPOT_HIP_VERSION 100
+
+int spot_version(void);
+const char* spot_last_error(void);
+
+/* ---- pre-input --------------------------------------------------------- */
+
+/* NormJitter + Normalize, ltr/models/pre_input/necessary_preprocess.py:54-67,86-91.
+ * out = (clamp(float(images) * scale[b], 0, 1) - mean[c]) / std[c].
+ * images [B,3,H,W] uint8, scale [B] (brightness/255; NULL = 1/255), mean3/std3 HOST
+ * pointers to 3 floats, out [B,3,H,W] float.  H*W must be a multiple of 16. */
+int spot_preprocess_u8_f32(const unsigned char* images, const float* scale, const float* mean3,
+                           const float* std3, float* out, int B, int C, int H, int W, hipStream_t stream);
+
+/* ---- pseudo-label path -------------------------------------------------- */
+
+/* TranstSparseActor._decode_teacher_result, ltr/actor/transt_sparse_actor.py:57-98.
+ * pred_logits [B,L,2], pred_boxes [B,L,4] (cx,cy,w,h in [0,1]), pred_ious [B,L],
+ * window [L] (outer product of two float32 Hanning vectors).
+ * -> best_bbox [B,4] (x0,y0,w,h px in the search crop; x0,y0 >= 0, w,h >= 1),
+ *    best_score [B], best_conf [B], best_idx [B]. */
+int spot_decode_teacher_f32(const float* pred_logits, const float* pred_boxes, const float* pred_ious,
+                            const float* window, double window_penalty, int img_w, int img_h,
+                            float* best_bbox, float* best_score, float* best_conf, int* best_idx,
+                            int B, int L, hipStream_t stream);
+
+/* SparseMiddleware.record_relay_results, ltr/data/middleware.py:49-152 with
+ * recover_bbox_to_original / transform_image_to_crop, ltr/data/processing_utils.py:180-229.
+ * aug_success[b] = best_conf[b] >= confidence_threshold (float32 compare, middleware.py:117).
+ * box_extract [B,4], resize_factors [B] -> bbox_recovered [B,4], aug_anno [B,4], aug_success [B] (0/1). */
+int spot_middleware_filter_f32(const float* best_bbox, const float* best_conf,
+                               const float* unlabeled_box_extract, const float* unlabeled_resize_factors,
+                               const float* aug_box_extract, const float* aug_resize_factors,
+                               int search_sz, float confidence_threshold, float* bbox_recovered,
+                               float* aug_anno, unsigned char* aug_success, int B, hipStream_t stream);
+
+/* The two calls above fused into one launch (one workgroup per clip). */
+int spot_decode_filter_f32(const float* pred_logits, const float* pred_boxes, const float* pred_ious,
+                           const float* window, double window_penalty, int img_w, int img_h,
+                           const float* unlabeled_box_extract, const float* unlabeled_resize_factors,
+                           const float* aug_box_extract, const float* aug_resize_factors, int search_sz,
+                           float confidence_threshold, float* best_bbox, float* best_score,
+                           float* best_conf, int* best_idx, float* bbox_recovered, float* aug_anno,
+                           unsigned char* aug_success, int B, int L, hipStream_t stream);
+
+/* Keep/refill rule of LTRSparseTrainer._sparse_training, ltr/trainers/ltr_sparse_trainer.py:334-357:
+ * kept rows in order, then cyclic repetition up to n_out rows.  gather_idx [n_out] (-1 everywhere when
+ * nothing was kept: the caller skips the iteration, :328-332), n_keep [1].  n_in <= 12288. */
+int spot_compact_indices(const unsigned char* aug_success, int n_in, int* gather_idx, int n_out,
+                         int* n_keep, hipStream_t stream);
+
+/* dst[r] = src[gather_idx[r]] for rows of row_bytes bytes (the torch.stack/cat of :342-357). */
+int spot_gather_rows(const void* src, void* dst, const int* gather_idx, int n_rows, long row_bytes,
+                     hipStream_t stream);
+
+/* ---- teacher EMA --------------------------------------------------------- */
+
+/* _update_teacher_model, ltr/actor/transt_sparse_actor.py:11-33, on flat storage:
+ * teacher = student * (1 - keep_rate) + teacher * keep_rate. */
+int spot_ema_lerp_f32(float* teacher, const float* student, long n, double keep_rate, hipStream_t stream);
+/* same for int64 buffers (BatchNorm num_batches_tracked): float32 arithmetic, truncated. */
+int spot_ema_lerp_i64(long long* teacher, const long long* student, int n, double keep_rate,
+                      hipStream_t stream);
+
+/* ---- boxes ---------------------------------------------------------------- */
+
+/* box_iou_pair_xyxy / generalized_box_iou_pair_xyxy (+ box_cxcywh_to_xyxy when cxcywh != 0),
+ * ltr/utils/box_ops.py:9-13,105-156.  boxes [P,4]; any of giou/iou/union_area may be NULL. */
+int spot_box_iou_pair_f32(const float* boxes1, const float* boxes2, int cxcywh, float* giou, float* iou,
+                          float* union_area, int P, hipStream_t stream);
+/* gradient of (giou, iou) w.r.t. boxes1 (cxcywh) for upstream d_giou / d_iou (either may be NULL). */
+int spot_box_giou_pair_bwd_f32(const float* boxes1_cxcywh, const float* boxes2_cxcywh, const float* d_giou,
+                               const float* d_iou, float* d_boxes1, int P, hipStream_t stream);
+
+/* ---- depthwise cross-correlation head ------------------------------------- */
+
+/* xcorr_depthwise, ltr/models/neck/ocean_fusion.py:238-247.  x [planes,hx,wx], kernel [planes,hz,wz]
+ * (planes = B*C) -> out [planes, hx-hz+1, wx-wz+1]. */
+int spot_xcorr_depthwise_f32(const float* x, const float* kernel, float* out, int planes, int hx, int wx,
+                             int hz, int wz, hipStream_t stream);
+/* GroupDW.forward, ltr/models/neck/ocean_fusion.py:211-235: sum_i softmax(weight3)_i * xcorr(x_i, z_i) with
+ * branch shapes (hx,wx)/(hz,wz), (hx-2,wx)/(hz-2,wz), (hx,wx-2)/(hz,wz-2) (matrix, :117-171). */
+int spot_groupdw_f32(const float* x11, const float* x12, const float* x21, const float* z11,
+                     const float* z12, const float* z21, const float* weight3, float* out, int planes,
+                     int hx, int wx, int hz, int wz, hipStream_t stream);
+
+/* ---- dense contractions (fp32 on the matrix cores) ------------------------- */
+
+/* One GEMM problem: C[M,N] (+)= alpha * opA(A) * opB(B) + epilogue.  Carries nn.Linear forward
+ * (F.linear: transt_fusion.py:151,234,240; transt_model.py:308-309), the packed in-/out-projections
+ * of nn.MultiheadAttention (:121,172-175), the 1x1 input_proj conv (transt_model.py:49,274-275)
+ * and all of their gradients.
+ *   transA = 0: A[m*lda + k]        transA = 1: A[k*lda + m]
+ *   transB = 0: B[n*ldb + k] (an nn.Linear weight [N,K])   transB = 1: B[k*ldb + n]
+ *   batch > 1: problem z uses A + z*strideA, B + z*strideB, C + z*strideC, residual + z*strideRes.
+ *   kseg > 0: the K range is cut into segments of kseg (multiple of 32); segment s reads A + s*segA,
+ *             B + s*segB with k counted from 0 again (a reduction that runs over several batch slabs).
+ *   splitk > 1: K is split over splitk workgroups that add atomically into C (set accumulate = 1 and
+ *             clear C first); not combinable with relu / mask.
+ * Epilogue order: v = alpha*acc + bias[n] + rowbias[(m % rb_rows)*ldrb + n]; relu; v = mask[m*ldmask+n] > 0 ? v : 0;
+ *                 v += residual[m*ldres + n]; C = v or C += v. */
+typedef struct spot_gemm_desc {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K, batch;
+    int transA, transB;
+    long lda, ldb, ldc;
+    long strideA, strideB, strideC;
+    int kseg;
+    long segA, segB;
+    int splitk;
+    float alpha;
+    int accumulate;
+    const float* bias;
+    const float* rowbias;
+    int rb_rows;
+    long ldrb;
+    int relu;
+    const float* mask;
+    long ldmask;
+    const float* residual;
+    long ldres, strideRes;
+} spot_gemm_desc;
+
+int spot_gemm_f32(const spot_gemm_desc* desc /* host */, hipStream_t stream);
+
+/* out[n] += sum_m x[m*ld + n]  (bias gradients); out must be cleared by the caller. */
+int spot_colsum_f32(const float* x, long ld, float* out, long rows, int N, hipStream_t stream);
+
+/* ---- attention core ---------------------------------------------------------- */
+
+/* softmax(scale * Q K^T + key_padding_mask) V per head, the middle of nn.MultiheadAttention as called at
+ * ltr/models/neck/transt_fusion.py:145-148,212-213,218-219,223-230.  q [B,Lq,nhead*32] with row stride ldq
+ * (so q/k/v may be column windows of a packed projection buffer), k,v [B,Lk,nhead*32], out [B,Lq,nhead*32];
+ * lse [B,nhead,Lq] (log-sum-exp of the scaled scores, NULL to skip; needed by the backward);
+ * key_padding_mask [B,Lk] bytes, non-zero = ignore key, or NULL.  head_dim must be 32. */
+int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                     float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B,
+                     int Lq, int Lk, int nhead, int head_dim, float scale, hipStream_t stream);
+
+/* Gradient of the above w.r.t. q, k, v given d_out.  delta_ws: workspace [B,nhead,Lq] floats.
+ * dq is accumulated with atomic adds and is cleared by this call. */
+int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                     const float* out, long ldo, const float* d_out, long lddo, const float* lse,
+                     const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq,
+                     float* dk, long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead,
+                     int head_dim, float scale, hipStream_t stream);
+
+/* ---- LayerNorm ----------------------------------------------------------------- */
+
+/* nn.LayerNorm over the last dim (transt_fusion.py:127-128,185-190,26): y = (x-mean)*rstd*gamma + beta.
+ * x,y [rows,C]; mean,rstd [rows] (NULL to skip).  C multiple of 4, <= 1024. */
+int spot_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                           float* rstd, long rows, int C, float eps, hipStream_t stream);
+/* dx, and dgamma/dbeta ADDED into caller-cleared buffers (either may be NULL). */
+int spot_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd,
+                           const float* gamma, float* dx, float* dgamma, float* dbeta, long rows, int C,
+                           hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPOT_HIP_H */

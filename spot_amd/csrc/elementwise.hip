@@ -1,0 +1,239 @@
+// HBM-bound elementwise kernels of the hot path: uint8 crop normalisation,
+// teacher EMA, paired box IoU / GIoU (forward + backward).
+#include "common.h"
+#include "../../include/spot_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// uint8 -> normalised float (ltr/models/pre_input/necessary_preprocess.py:54-67,86-91)
+//   out = (clamp(float(x) * scale[b], 0, 1) - mean[c]) / std[c]
+// 16 pixels per lane: one 16-byte load, four 16-byte stores.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint4* __restrict__ img, const float* __restrict__ scale,
+                                                         float3 mean, float3 stdv, float4* __restrict__ out,
+                                                         long plane_vec /* H*W/16 */, int C, long total_vec) {
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < total_vec; v += (long)gridDim.x * 256) {
+        const long plane = v / plane_vec;
+        const int c = (int)(plane % C);
+        const int b = (int)(plane / C);
+        const float s = scale ? scale[b] : (1.0f / 255.0f);
+        const float m = c == 0 ? mean.x : (c == 1 ? mean.y : mean.z);
+        const float d = c == 0 ? stdv.x : (c == 1 ? stdv.y : stdv.z);
+        const uint4 p = img[v];
+        const unsigned w[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 o;
+            o.x = __fdiv_rn(__fsub_rn(fminf(fmaxf(__fmul_rn((float)(w[k] & 0xff), s), 0.f), 1.f), m), d);
+            o.y = __fdiv_rn(__fsub_rn(fminf(fmaxf(__fmul_rn((float)((w[k] >> 8) & 0xff), s), 0.f), 1.f), m), d);
+            o.z = __fdiv_rn(__fsub_rn(fminf(fmaxf(__fmul_rn((float)((w[k] >> 16) & 0xff), s), 0.f), 1.f), m), d);
+            o.w = __fdiv_rn(__fsub_rn(fminf(fmaxf(__fmul_rn((float)(w[k] >> 24), s), 0.f), 1.f), m), d);
+            out[v * 4 + k] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// teacher EMA (ltr/actor/transt_sparse_actor.py:11-33) on flat parameter storage
+//   t = s * (1 - keep) + t * keep      (two rounded products, one rounded sum)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ema_kernel(float4* __restrict__ t, const float4* __restrict__ s, long n_vec,
+                                                  float* __restrict__ t_tail, const float* __restrict__ s_tail,
+                                                  int n_tail, float omk, float k) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long)gridDim.x * 256) {
+        float4 a = t[i];
+        const float4 b = s[i];
+        a.x = __fadd_rn(__fmul_rn(b.x, omk), __fmul_rn(a.x, k));
+        a.y = __fadd_rn(__fmul_rn(b.y, omk), __fmul_rn(a.y, k));
+        a.z = __fadd_rn(__fmul_rn(b.z, omk), __fmul_rn(a.z, k));
+        a.w = __fadd_rn(__fmul_rn(b.w, omk), __fmul_rn(a.w, k));
+        t[i] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n_tail)
+        t_tail[threadIdx.x] = __fadd_rn(__fmul_rn(s_tail[threadIdx.x], omk), __fmul_rn(t_tail[threadIdx.x], k));
+}
+
+// integer buffers (BatchNorm num_batches_tracked): the reference's expression
+// promotes to float32 and load_state_dict truncates back to int64.
+__global__ void ema_i64_kernel(long long* __restrict__ t, const long long* __restrict__ s, int n, float omk, float k) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = (long long)__fadd_rn(__fmul_rn((float)s[i], omk), __fmul_rn((float)t[i], k));
+}
+
+// ---------------------------------------------------------------------------
+// paired IoU / GIoU on cxcywh boxes (ltr/utils/box_ops.py:9-13,105-156)
+// ---------------------------------------------------------------------------
+struct XYXY {
+    float x0, y0, x1, y1;
+};
+__device__ __forceinline__ XYXY to_xyxy(float4 b) {
+    return XYXY{__fsub_rn(b.x, __fmul_rn(0.5f, b.z)), __fsub_rn(b.y, __fmul_rn(0.5f, b.w)),
+                __fadd_rn(b.x, __fmul_rn(0.5f, b.z)), __fadd_rn(b.y, __fmul_rn(0.5f, b.w))};
+}
+
+template <bool CXCYWH>
+__global__ __launch_bounds__(256) void giou_fwd_kernel(const float4* __restrict__ b1, const float4* __restrict__ b2,
+                                                       float* __restrict__ giou, float* __restrict__ iou,
+                                                       float* __restrict__ uni, int P) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    XYXY a, b;
+    if (CXCYWH) {
+        a = to_xyxy(b1[i]);
+        b = to_xyxy(b2[i]);
+    } else {
+        float4 p = b1[i], q = b2[i];
+        a = XYXY{p.x, p.y, p.z, p.w};
+        b = XYXY{q.x, q.y, q.z, q.w};
+    }
+    const float a1 = __fmul_rn(__fsub_rn(a.x1, a.x0), __fsub_rn(a.y1, a.y0));
+    const float a2 = __fmul_rn(__fsub_rn(b.x1, b.x0), __fsub_rn(b.y1, b.y0));
+    const float iw = fmaxf(__fsub_rn(fminf(a.x1, b.x1), fmaxf(a.x0, b.x0)), 0.f);
+    const float ih = fmaxf(__fsub_rn(fminf(a.y1, b.y1), fmaxf(a.y0, b.y0)), 0.f);
+    const float inter = __fmul_rn(iw, ih);
+    const float u = __fsub_rn(__fadd_rn(a1, a2), inter);
+    const float io = __fdiv_rn(inter, u);
+    if (iou) iou[i] = io;
+    if (uni) uni[i] = u;
+    if (giou) {
+        const float hw = fmaxf(__fsub_rn(fmaxf(a.x1, b.x1), fminf(a.x0, b.x0)), 0.f);
+        const float hh = fmaxf(__fsub_rn(fmaxf(a.y1, b.y1), fminf(a.y0, b.y0)), 0.f);
+        const float area = __fmul_rn(hw, hh);
+        giou[i] = __fsub_rn(io, __fdiv_rn(__fsub_rn(area, u), area));
+    }
+}
+
+// Gradient of (giou, iou) w.r.t. the first box set (cxcywh), given upstream
+// d_giou[P] and d_iou[P] (either may be null).  Sub-gradients follow ATen:
+// max/min send the gradient to the selected operand and split it in half on
+// ties; clamp(min=0) passes the gradient where the argument is >= 0.
+__device__ __forceinline__ void dmax(float g, float p, float q, float& gp, float& gq) {
+    if (p > q) gp += g;
+    else if (p < q) gq += g;
+    else { gp += 0.5f * g; gq += 0.5f * g; }
+}
+__device__ __forceinline__ void dmin(float g, float p, float q, float& gp, float& gq) {
+    if (p < q) gp += g;
+    else if (p > q) gq += g;
+    else { gp += 0.5f * g; gq += 0.5f * g; }
+}
+
+__global__ __launch_bounds__(256) void giou_bwd_kernel(const float4* __restrict__ b1, const float4* __restrict__ b2,
+                                                       const float* __restrict__ d_giou, const float* __restrict__ d_iou,
+                                                       float4* __restrict__ d_b1, int P) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float4 p = b1[i];
+    const XYXY a = to_xyxy(p), b = to_xyxy(b2[i]);
+    const float w1 = a.x1 - a.x0, h1 = a.y1 - a.y0;
+    const float a1 = w1 * h1, a2 = (b.x1 - b.x0) * (b.y1 - b.y0);
+    const float ix0 = fmaxf(a.x0, b.x0), iy0 = fmaxf(a.y0, b.y0), ix1 = fminf(a.x1, b.x1), iy1 = fminf(a.y1, b.y1);
+    const float iwr = ix1 - ix0, ihr = iy1 - iy0;
+    const float iw = fmaxf(iwr, 0.f), ih = fmaxf(ihr, 0.f);
+    const float inter = iw * ih;
+    const float u = a1 + a2 - inter;
+    const float hx0 = fminf(a.x0, b.x0), hy0 = fminf(a.y0, b.y0), hx1 = fmaxf(a.x1, b.x1), hy1 = fmaxf(a.y1, b.y1);
+    const float hwr = hx1 - hx0, hhr = hy1 - hy0;
+    const float hw = fmaxf(hwr, 0.f), hh = fmaxf(hhr, 0.f);
+    const float area = hw * hh;
+    const float gg = d_giou ? d_giou[i] : 0.f;
+    const float gi = (d_iou ? d_iou[i] : 0.f) + gg;      // giou = iou - (area-u)/area
+    // iou = inter/u ; giou extra term -(area-u)/area = -1 + u/area
+    float g_inter = gi / u;
+    float g_u = -gi * inter / (u * u) + gg / area;
+    float g_area = -gg * u / (area * area);
+    // u = a1 + a2 - inter
+    float g_a1 = g_u;
+    g_inter -= g_u;
+    // inter = iw*ih with clamps
+    float g_iwr = (iwr >= 0.f) ? g_inter * ih : 0.f;
+    float g_ihr = (ihr >= 0.f) ? g_inter * iw : 0.f;
+    float g_hwr = (hwr >= 0.f) ? g_area * hh : 0.f;
+    float g_hhr = (hhr >= 0.f) ? g_area * hw : 0.f;
+    float gx0 = 0.f, gy0 = 0.f, gx1 = 0.f, gy1 = 0.f, dump = 0.f;
+    dmin(g_iwr, a.x1, b.x1, gx1, dump);
+    dmax(-g_iwr, a.x0, b.x0, gx0, dump);
+    dmin(g_ihr, a.y1, b.y1, gy1, dump);
+    dmax(-g_ihr, a.y0, b.y0, gy0, dump);
+    dmax(g_hwr, a.x1, b.x1, gx1, dump);
+    dmin(-g_hwr, a.x0, b.x0, gx0, dump);
+    dmax(g_hhr, a.y1, b.y1, gy1, dump);
+    dmin(-g_hhr, a.y0, b.y0, gy0, dump);
+    // a1 = (x1-x0)*(y1-y0)
+    gx1 += g_a1 * h1; gx0 -= g_a1 * h1;
+    gy1 += g_a1 * w1; gy0 -= g_a1 * w1;
+    // xyxy -> cxcywh
+    d_b1[i] = make_float4(gx0 + gx1, gy0 + gy1, 0.5f * (gx1 - gx0), 0.5f * (gy1 - gy0));
+}
+
+}  // namespace
+
+extern "C" int spot_preprocess_u8_f32(const unsigned char* images, const float* scale, const float* mean3,
+                                      const float* std3, float* out, int B, int C, int H, int W,
+                                      hipStream_t stream) {
+    SPOT_CHECK_ARG(images && out && mean3 && std3, "preprocess: null pointer");
+    SPOT_CHECK_ARG(B >= 0 && C == 3 && H > 0 && W > 0, "preprocess: bad shape B=%d C=%d H=%d W=%d (C must be 3)", B, C,
+                   H, W);
+    SPOT_CHECK_ARG(((long)H * W) % 16 == 0, "preprocess: H*W=%ld must be a multiple of 16", (long)H * W);
+    SPOT_CHECK_ARG((uintptr_t)images % 16 == 0 && (uintptr_t)out % 16 == 0, "preprocess: buffers must be 16-byte aligned");
+    if (B == 0) return SPOT_OK;
+    const long plane_vec = (long)H * W / 16;
+    const long total = plane_vec * C * B;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    preprocess_kernel<<<grid, 256, 0, stream>>>((const uint4*)images, scale, make_float3(mean3[0], mean3[1], mean3[2]),
+                                                make_float3(std3[0], std3[1], std3[2]), (float4*)out, plane_vec, C,
+                                                total);
+    SPOT_CHECK_LAUNCH("preprocess");
+    return SPOT_OK;
+}
+
+extern "C" int spot_ema_lerp_f32(float* teacher, const float* student, long n, double keep_rate, hipStream_t stream) {
+    SPOT_CHECK_ARG(teacher && student && n >= 0, "ema_lerp: bad arguments");
+    SPOT_CHECK_ARG((uintptr_t)teacher % 16 == 0 && (uintptr_t)student % 16 == 0, "ema_lerp: buffers must be 16-byte aligned");
+    if (n == 0) return SPOT_OK;
+    const long n_vec = n / 4;
+    const int n_tail = (int)(n - n_vec * 4);
+    int grid = (int)((n_vec + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    ema_kernel<<<grid, 256, 0, stream>>>((float4*)teacher, (const float4*)student, n_vec, teacher + n_vec * 4,
+                                         student + n_vec * 4, n_tail, (float)(1.0 - keep_rate), (float)keep_rate);
+    SPOT_CHECK_LAUNCH("ema_lerp");
+    return SPOT_OK;
+}
+
+extern "C" int spot_ema_lerp_i64(long long* teacher, const long long* student, int n, double keep_rate,
+                                 hipStream_t stream) {
+    SPOT_CHECK_ARG(teacher && student && n >= 0, "ema_lerp_i64: bad arguments");
+    if (n == 0) return SPOT_OK;
+    ema_i64_kernel<<<(n + 255) / 256, 256, 0, stream>>>(teacher, student, n, (float)(1.0 - keep_rate), (float)keep_rate);
+    SPOT_CHECK_LAUNCH("ema_lerp_i64");
+    return SPOT_OK;
+}
+
+extern "C" int spot_box_iou_pair_f32(const float* boxes1, const float* boxes2, int cxcywh, float* giou, float* iou,
+                                     float* union_area, int P, hipStream_t stream) {
+    SPOT_CHECK_ARG(boxes1 && boxes2 && P >= 0, "box_iou_pair: bad arguments");
+    SPOT_CHECK_ARG(giou || iou || union_area, "box_iou_pair: no output requested");
+    if (P == 0) return SPOT_OK;
+    const int grid = (P + 255) / 256;
+    if (cxcywh)
+        giou_fwd_kernel<true><<<grid, 256, 0, stream>>>((const float4*)boxes1, (const float4*)boxes2, giou, iou, union_area, P);
+    else
+        giou_fwd_kernel<false><<<grid, 256, 0, stream>>>((const float4*)boxes1, (const float4*)boxes2, giou, iou, union_area, P);
+    SPOT_CHECK_LAUNCH("box_iou_pair");
+    return SPOT_OK;
+}
+
+extern "C" int spot_box_giou_pair_bwd_f32(const float* boxes1_cxcywh, const float* boxes2_cxcywh, const float* d_giou,
+                                          const float* d_iou, float* d_boxes1, int P, hipStream_t stream) {
+    SPOT_CHECK_ARG(boxes1_cxcywh && boxes2_cxcywh && d_boxes1 && P >= 0, "box_giou_pair_bwd: bad arguments");
+    SPOT_CHECK_ARG(d_giou || d_iou, "box_giou_pair_bwd: no upstream gradient");
+    if (P == 0) return SPOT_OK;
+    giou_bwd_kernel<<<(P + 255) / 256, 256, 0, stream>>>((const float4*)boxes1_cxcywh, (const float4*)boxes2_cxcywh,
+                                                         d_giou, d_iou, (float4*)d_boxes1, P);
+    SPOT_CHECK_LAUNCH("box_giou_pair_bwd");
+    return SPOT_OK;
+}

@@ -1,0 +1,264 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// bit-identical to an fmaf chain, 64 FLOP/clk/SIMD).  It carries every dense
+// contraction of the fusion network and the heads, forward and backward:
+//   nn.Linear / in-proj / out-proj / FFN / MLP heads / 1x1 input_proj
+//   (ltr/models/neck/transt_fusion.py:121-133,172-199; transt_model.py:47-56,296-310).
+//
+//   C[M,N] (+)= alpha * opA(A) * opB(B)  (+ bias[n]) (+ rowbias[m % rb_rows][n]) -> relu? -> (* mask>0)? (+ residual)
+//
+// Operand layouts (row-major storage, leading dimension in elements):
+//   A: "MK" = A[m*lda + k]   or "KM" = A[k*lda + m]   (a transposed activation / NCHW feature map)
+//   B: "NK" = B[n*ldb + k]   (an nn.Linear weight)  or "KN" = B[k*ldb + n]
+// Tiling: 128x128x32 per 256-thread workgroup, 4 waves as 2x2, each wave a 2x2
+// grid of 32x32 MFMA tiles (64 accumulator VGPRs).  Tiles are staged
+// global -> registers -> LDS, double-buffered with one barrier per k-tile: the
+// next tile's global loads are issued before the 64 MFMAs of the current one,
+// the LDS writes after them.  LDS keeps the operand's own storage order
+// (k-contiguous rows padded to 36 floats for conflict-free 16-byte fragment
+// reads; m/n-contiguous rows read with 4-byte reads), so no transposes happen
+// anywhere.  Within an 8-wide k group lane half h takes k = 4h..4h+3: the
+// matrix instruction's two k slots then cover {j, 4+j}, j = 0..3, on both
+// operands, which is a pure re-ordering of the k sum.
+#include "common.h"
+#include "../../include/spot_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int KPAD = BK + 4;    // k-contiguous LDS row stride (floats)
+constexpr int MPAD = BM + 4;    // m/n-contiguous LDS row stride (floats)
+constexpr int TILE_F = 128 * KPAD;  // floats per operand tile buffer (>= 32*MPAD)
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    long strideA, strideB, strideC;   // per batch (grid.z / splitk)
+    int kseg; long segA, segB;        // K is cut in segments of kseg; segment s adds s*segA / s*segB
+    int splitk;
+    float alpha;
+    int accumulate;                   // C += result (plain read-modify-write; atomic when splitk > 1)
+    const float* bias;                // [N] or null
+    const float* rowbias; int rb_rows; long ldrb;   // [rb_rows, N] indexed by m % rb_rows
+    int relu;
+    const float* mask; long ldmask;   // multiply by (mask[m][n] > 0)
+    const float* residual; long ldres; long strideRes;
+};
+
+template <int LAYOUT_KCONTIG, bool ALIGNED>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int r0, int k0, int R, int K,
+                                          float4 (&st)[4], int tid) {
+    // LAYOUT_KCONTIG: element (r,k) at P[r*ld + k], tile 128 rows x 32 k, float4 along k
+    // else          : element (r,k) at P[k*ld + r], tile 32 k x 128 rows, float4 along r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        int r, k;
+        if (LAYOUT_KCONTIG) { r = r0 + (f >> 3); k = k0 + ((f & 7) << 2); }
+        else                { k = k0 + (f >> 5); r = r0 + ((f & 31) << 2); }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (LAYOUT_KCONTIG) {
+            if (r < R) {
+                const float* p = P + (long)r * ld + k;
+                if (ALIGNED && k + 3 < K) v = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (k < K) v.x = p[0];
+                    if (k + 1 < K) v.y = p[1];
+                    if (k + 2 < K) v.z = p[2];
+                    if (k + 3 < K) v.w = p[3];
+                }
+            }
+        } else {
+            if (k < K) {
+                const float* p = P + (long)k * ld + r;
+                if (ALIGNED && r + 3 < R) v = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (r < R) v.x = p[0];
+                    if (r + 1 < R) v.y = p[1];
+                    if (r + 2 < R) v.z = p[2];
+                    if (r + 3 < R) v.w = p[3];
+                }
+            }
+        }
+        st[i] = v;
+    }
+}
+
+template <int LAYOUT_KCONTIG>
+__device__ __forceinline__ void store_tile(float* lds, const float4 (&st)[4], int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        if (LAYOUT_KCONTIG) *reinterpret_cast<float4*>(lds + (f >> 3) * KPAD + ((f & 7) << 2)) = st[i];
+        else                *reinterpret_cast<float4*>(lds + (f >> 5) * MPAD + ((f & 31) << 2)) = st[i];
+    }
+}
+
+// fragment for one 32-row tile and one 8-wide k group: 4 floats, element j <-> k = g*8 + 4h + j
+template <int LAYOUT_KCONTIG>
+__device__ __forceinline__ float4 read_frag(const float* lds, int row, int g, int h) {
+    if (LAYOUT_KCONTIG) return *reinterpret_cast<const float4*>(lds + row * KPAD + g * 8 + 4 * h);
+    const float* p = lds + (g * 8 + 4 * h) * MPAD + row;
+    return make_float4(p[0], p[MPAD], p[2 * MPAD], p[3 * MPAD]);
+}
+
+template <int LA, int LB, bool ALIGNED>   // LA: 1 = MK (k-contiguous), 0 = KM;  LB: 1 = NK, 0 = KN
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
+    auto As = [&](int buf) { return lds + buf * TILE_F; };
+    auto Bs = [&](int buf) { return lds + (2 + buf) * TILE_F; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+
+    // XCD-aware tile order: workgroups that land on one XCD (ids equal mod 8) walk a contiguous
+    // range of tiles, n fastest, so the A row panel a tile needs is already in that XCD's L2.
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM, nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, x = bid & 7, loc = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+    const int zb = blockIdx.z / g.splitk, zs = blockIdx.z % g.splitk;
+
+    const float* A = g.A + zb * g.strideA;
+    const float* B = g.B + zb * g.strideB;
+    const int nkt = (g.K + BK - 1) / BK;
+    const int per = (nkt + g.splitk - 1) / g.splitk;
+    const int kt0 = zs * per, kt1 = min(nkt, kt0 + per);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+    float4 sa[4], sb[4];
+    auto fetch = [&](int kt) {
+        const int k = kt * BK;
+        const int seg = k / g.kseg, kin = k - seg * g.kseg;
+        load_tile<LA, ALIGNED>(A + seg * g.segA, g.lda, m0, kin, g.M, min(g.kseg, g.K - seg * g.kseg), sa, tid);
+        load_tile<LB, ALIGNED>(B + seg * g.segB, g.ldb, n0, kin, g.N, min(g.kseg, g.K - seg * g.kseg), sb, tid);
+    };
+
+    if (kt0 < kt1) {
+        fetch(kt0);
+        store_tile<LA>(As(0), sa, tid);
+        store_tile<LB>(Bs(0), sb, tid);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
+        if (more) fetch(kt + 1);
+        const float* as = As(cur);
+        const float* bs = Bs(cur);
+#pragma unroll
+        for (int gk = 0; gk < BK / 8; ++gk) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = read_frag<LA>(as, wm * 64 + t * 32 + l31, gk, h);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) b[u] = read_frag<LB>(bs, wn * 64 + u * 32 + l31, gk, h);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
+                }
+        }
+        if (more) {
+            store_tile<LA>(As(cur ^ 1), sa, tid);
+            store_tile<LB>(Bs(cur ^ 1), sb, tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: accumulator element e of tile (t,u): row = (e&3) + 8*(e>>2) + 4h, col = lane&31
+    float* C = g.C + zb * g.strideC;
+    const float* res = (g.residual && zs == 0) ? g.residual + zb * g.strideRes : nullptr;
+    const float* rowbias = zs == 0 ? g.rowbias : nullptr;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int n = n0 + wn * 64 + u * 32 + l31;
+        if (n >= g.N) continue;
+        const float bv = (g.bias && zs == 0) ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                float v = acc[t][u][e] * g.alpha + bv;
+                if (rowbias) v += rowbias[(long)(m % g.rb_rows) * g.ldrb + n];
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.mask) v = g.mask[(long)m * g.ldmask + n] > 0.f ? v : 0.f;
+                if (res) v += res[(long)m * g.ldres + n];
+                float* cp = C + (long)m * g.ldc + n;
+                if (g.splitk > 1) atomicAdd(cp, v);
+                else if (g.accumulate) *cp += v;
+                else *cp = v;
+            }
+        }
+    }
+}
+
+template <int LA, int LB>
+int launch(const GemmArgs& a, int batch, bool aligned, hipStream_t stream) {
+    const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
+    dim3 grid(ntm * ntn, 1, batch * a.splitk);
+    if (aligned) gemm_kernel<LA, LB, true><<<grid, 256, 0, stream>>>(a);
+    else gemm_kernel<LA, LB, false><<<grid, 256, 0, stream>>>(a);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
+    SPOT_CHECK_ARG(d, "gemm: null descriptor");
+    SPOT_CHECK_ARG(d->A && d->B && d->C, "gemm: null operand");
+    SPOT_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0 && d->batch >= 1, "gemm: bad shape M=%d N=%d K=%d batch=%d",
+                   d->M, d->N, d->K, d->batch);
+    if (d->M == 0 || d->N == 0) return SPOT_OK;
+    GemmArgs a;
+    a.A = d->A; a.B = d->B; a.C = d->C;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
+    a.strideA = d->strideA; a.strideB = d->strideB; a.strideC = d->strideC;
+    a.kseg = d->kseg > 0 ? d->kseg : (d->K > 0 ? d->K : 1);
+    a.segA = d->segA; a.segB = d->segB;
+    a.splitk = d->splitk > 1 ? d->splitk : 1;
+    a.alpha = d->alpha;
+    a.accumulate = d->accumulate;
+    a.bias = d->bias;
+    a.rowbias = d->rowbias; a.rb_rows = d->rb_rows > 0 ? d->rb_rows : 1; a.ldrb = d->ldrb;
+    a.relu = d->relu;
+    a.mask = d->mask; a.ldmask = d->ldmask;
+    a.residual = d->residual; a.ldres = d->ldres; a.strideRes = d->strideRes;
+    SPOT_CHECK_ARG(a.kseg % BK == 0 || a.kseg >= a.K, "gemm: kseg=%d must be a multiple of %d", a.kseg, BK);
+    if (a.splitk > 1) {
+        SPOT_CHECK_ARG(!a.relu && !a.mask, "gemm: split-K cannot be combined with relu/mask epilogues");
+        SPOT_CHECK_ARG(a.accumulate, "gemm: split-K accumulates atomically into C; zero C and set accumulate=1");
+    }
+    const int ta = d->transA ? 0 : 1, tb = d->transB ? 0 : 1;   // template arg 1 = k-contiguous
+    // 16-byte vector loads need aligned bases/strides and a contiguous extent that is a multiple of 4
+    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    bool aligned = al(a.A) && al(a.B) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && (a.strideA % 4 == 0) &&
+                   (a.strideB % 4 == 0) && (a.segA % 4 == 0) && (a.segB % 4 == 0);
+    aligned = aligned && (ta ? (a.K % 4 == 0 && a.kseg % 4 == 0) : (a.M % 4 == 0));
+    aligned = aligned && (tb ? (a.K % 4 == 0 && a.kseg % 4 == 0) : (a.N % 4 == 0));
+    if (ta && tb) launch<1, 1>(a, d->batch, aligned, stream);
+    else if (ta && !tb) launch<1, 0>(a, d->batch, aligned, stream);
+    else if (!ta && tb) launch<0, 1>(a, d->batch, aligned, stream);
+    else launch<0, 0>(a, d->batch, aligned, stream);
+    SPOT_CHECK_LAUNCH("gemm");
+    return SPOT_OK;
+}

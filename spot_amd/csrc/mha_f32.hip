@@ -1,0 +1,414 @@
+// Fused multi-head attention core, fp32 on the matrix cores, head dim 32.
+//
+// Replaces the QK^T -> key-padding mask -> softmax -> (dropout) -> PV middle of
+// nn.MultiheadAttention as the fusion layers call it
+// (ltr/models/neck/transt_fusion.py:145-148,212-213,218-219,223-230): ECA
+// self-attention (256x256, 1024x1024 tokens) and CFA template x search
+// cross-attention (256x1024, 1024x256).  The in/out projections are GEMMs
+// (gemm_f32.hip); the B*8*Lq*Lk score tensor the reference materialises never
+// leaves the chip.
+//
+// One 256-thread workgroup = 128 queries of one (clip, head); each wave owns 32
+// queries.  Keys/values stream through LDS in 64-key tiles (register-staged,
+// double-buffered).  Per 32-key block a wave issues
+//   S^T = K Q^T   16 x v_mfma_f32_32x32x2_f32  (keys on the accumulator rows, queries on the lanes)
+//   O^T += V^T P^T 16 x v_mfma_f32_32x32x2_f32 (the S^T accumulator IS the B operand: no shuffle, no LDS)
+// With queries on the lanes the online-softmax state (running max, sum, rescale
+// factor) is one scalar per lane and the row reductions are 15 in-register ops
+// plus one exchange with lane^32.
+#include "common.h"
+#include "../../include/spot_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int DH = 32;        // head dim
+constexpr int KT = 64;        // keys per LDS tile
+constexpr int KP = DH + 4;    // padded LDS row (floats)
+
+__device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+__global__ __launch_bounds__(256) void mha_fwd_kernel(
+    const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
+    float* __restrict__ O, long ldo, float* __restrict__ LSE, const unsigned char* __restrict__ kpm,
+    int Lq, int Lk, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * KP];
+    auto Ks = [&](int buf) { return lds + buf * 2 * KT * KP; };
+    auto Vs = [&](int buf) { return lds + buf * 2 * KT * KP + KT * KP; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    const bool qok = q < Lq;
+    const float c = scale * 1.4426950408889634f;   // scores are kept unscaled; exp2((s - m) * c)
+
+    // Q fragment: lane holds Q[q][16h .. 16h+15]
+    float qf[16];
+    {
+        const float* qp = Q + ((long)b * Lq + (qok ? q : 0)) * ldq + head * DH + 16 * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + 4 * i);
+            qf[4 * i] = v.x; qf[4 * i + 1] = v.y; qf[4 * i + 2] = v.z; qf[4 * i + 3] = v.w;
+        }
+    }
+    f32x16 o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const float* Kb = K + (long)b * Lk * ldk + head * DH;
+    const float* Vb = V + (long)b * Lk * ldv + head * DH;
+    const unsigned char* mb = kpm ? kpm + (long)b * Lk : nullptr;
+
+    float4 sk[2], sv[2];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            const int key = t * KT + (f >> 3), d4 = (f & 7) << 2;
+            if (key < Lk) {
+                sk[i] = *reinterpret_cast<const float4*>(Kb + (long)key * ldk + d4);
+                sv[i] = *reinterpret_cast<const float4*>(Vb + (long)key * ldv + d4);
+            } else {
+                sk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                sv[i] = sk[i];
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            *reinterpret_cast<float4*>(Ks(buf) + (f >> 3) * KP + ((f & 7) << 2)) = sk[i];
+            *reinterpret_cast<float4*>(Vs(buf) + (f >> 3) * KP + ((f & 7) << 2)) = sv[i];
+        }
+    };
+
+    const int ntile = (Lk + KT - 1) / KT;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        const bool more = t + 1 < ntile;
+        if (more) fetch(t + 1);
+#pragma unroll
+        for (int sub = 0; sub < KT / 32; ++sub) {
+            const int key0 = t * KT + sub * 32;
+            if (key0 >= Lk) break;
+            const float* ks = Ks(cur) + sub * 32 * KP;
+            const float* vs = Vs(cur) + sub * 32 * KP;
+            // ---- S^T = K Q^T
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+            float kf[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(ks + l31 * KP + 16 * h + 4 * i);
+                kf[4 * i] = v.x; kf[4 * i + 1] = v.y; kf[4 * i + 2] = v.z; kf[4 * i + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[j], s, 0, 0, 0);
+            // ---- mask, online softmax (per lane = per query)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = key0 + acc_row(e, h);
+                const bool dead = key >= Lk || (mb && mb[key]);
+                s[e] = dead ? -INFINITY : s[e];
+                mx = fmaxf(mx, s[e]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c);   // m_run = -inf -> 0
+            float psum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s[e] = __builtin_amdgcn_exp2f((s[e] - m_use) * c);
+                psum += s[e];
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] *= alpha;
+            // ---- O^T += V^T P^T   (step e sums keys acc_row(e,0) and acc_row(e,1))
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float vf = vs[acc_row(e, h) * KP + l31];
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[e], o, 0, 0, 0);
+            }
+        }
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+    }
+    // each half summed its own 16 keys per block
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    if (qok) {
+        float* op = O + ((long)b * Lq + q) * ldo + head * DH;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<float4*>(op + 8 * gq + 4 * h) =
+                make_float4(o[4 * gq] * inv, o[4 * gq + 1] * inv, o[4 * gq + 2] * inv, o[4 * gq + 3] * inv);
+        if (LSE && h == 0) LSE[((long)b * H + head) * Lq + q] = m_run * scale + logf(l_tot);
+    }
+}
+
+}  // namespace
+
+extern "C" int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                                float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B,
+                                int Lq, int Lk, int nhead, int head_dim, float scale, hipStream_t stream) {
+    SPOT_CHECK_ARG(q && k && v && out, "mha_fwd: null pointer");
+    SPOT_CHECK_ARG(head_dim == DH, "mha_fwd: head_dim=%d unsupported (this build handles 32)", head_dim);
+    SPOT_CHECK_ARG(B >= 0 && Lq > 0 && Lk > 0 && nhead > 0, "mha_fwd: bad shape B=%d Lq=%d Lk=%d heads=%d", B, Lq, Lk, nhead);
+    SPOT_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 &&
+                       (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0,
+                   "mha_fwd: operands must be 16-byte aligned with row strides that are multiples of 4");
+    SPOT_CHECK_ARG(B <= 65535 && nhead <= 65535, "mha_fwd: B and heads must fit a grid dimension");
+    if (B == 0) return SPOT_OK;
+    dim3 grid((Lq + 127) / 128, nhead, B);
+    mha_fwd_kernel<<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk, nhead, scale);
+    SPOT_CHECK_LAUNCH("mha_fwd");
+    return SPOT_OK;
+}
+
+// ===========================================================================
+// Backward.  One workgroup owns 128 keys of one (clip, head): each wave keeps
+// the dK and dV tiles of its 32 keys in accumulators for the whole sweep over
+// the queries, so dK/dV need no cross-workgroup sum.  Scores are recomputed
+// from Q, K and the forward's log-sum-exp.  With the KEY on the lanes
+//   S  = Q K^T (init -LSE/scale)  and  dP = dO V^T (init -delta)
+// come out with queries on the accumulator rows, which makes P and dS directly
+// the A operands of  dV += P^T dO  and  dK += dS^T Q  (sums over the row index).
+// Only dS crosses LDS once (a per-wave 32x32 transpose) for  dQ += dS K,  which
+// leaves the chip as fp32 atomic adds shaped as two 128-byte row segments per
+// wave-instruction.
+// ===========================================================================
+namespace {
+
+constexpr int QP = DH + 4;   // padded LDS row
+
+__global__ __launch_bounds__(256) void mha_delta_kernel(const float* __restrict__ O, long ldo,
+                                                        const float* __restrict__ dO, long lddo,
+                                                        float* __restrict__ delta, int Lq, int H, long total) {
+    // one 8-lane group per (b, q, head): 8 x float4 = 32 channels
+    const long gidx = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int part = threadIdx.x & 7;
+    if (gidx >= total) return;
+    const int head = (int)(gidx % H);
+    const long bq = gidx / H;           // b*Lq + q
+    const float4 a = *reinterpret_cast<const float4*>(O + bq * ldo + head * DH + 4 * part);
+    const float4 g = *reinterpret_cast<const float4*>(dO + bq * lddo + head * DH + 4 * part);
+    float s = (a.x * g.x + a.y * g.y) + (a.z * g.z + a.w * g.w);
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (part == 0) {
+        const long b = bq / Lq, q = bq % Lq;
+        delta[(b * H + head) * Lq + q] = s;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
+    const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
+    const float* __restrict__ dO, long lddo, const float* __restrict__ LSE, const float* __restrict__ delta,
+    const unsigned char* __restrict__ kpm, float* __restrict__ dQ, long lddq, float* __restrict__ dK, long lddk,
+    float* __restrict__ dV, long lddv, int Lq, int Lk, int H, float scale) {
+    // LDS: 2 x (Q tile, dO tile) [32][QP], 2 x (lse, delta) [32], K tile [128][QP], 4 x dS [32][QP]
+    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * QP + 4 * 32 + 128 * QP + 4 * 32 * QP];
+    auto Qs = [&](int buf) { return lds + buf * 32 * QP; };
+    auto Gs = [&](int buf) { return lds + (2 + buf) * 32 * QP; };
+    auto Ls = [&](int buf) { return lds + 4 * 32 * QP + buf * 64; };
+    auto Ds = [&](int buf) { return lds + 4 * 32 * QP + buf * 64 + 32; };
+    float* Kt = lds + 4 * 32 * QP + 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    float* dSs = Kt + 128 * QP + wave * 32 * QP;
+
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int key_w0 = blockIdx.x * 128 + wave * 32;
+    const int key = key_w0 + l31;
+    const float c = scale * 1.4426950408889634f;
+    const float inv_scale = 1.f / scale;
+
+    const float* Qb = Q + (long)b * Lq * ldq + head * DH;
+    const float* Gb = dO + (long)b * Lq * lddo + head * DH;
+    const float* Lb = LSE + ((long)b * H + head) * Lq;
+    const float* Db = delta + ((long)b * H + head) * Lq;
+
+    // K tile of the workgroup into LDS (zero rows past Lk); V fragment straight to registers
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        const int kr = blockIdx.x * 128 + (f >> 3), d4 = (f & 7) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kr < Lk) v = *reinterpret_cast<const float4*>(K + ((long)b * Lk + kr) * ldk + head * DH + d4);
+        *reinterpret_cast<float4*>(Kt + (f >> 3) * QP + d4) = v;
+    }
+    float vf[16], kf[16];
+    const bool kvalid = key < Lk;
+    const bool kdead = !kvalid || (kpm && kpm[(long)b * Lk + key]);
+    {
+        const float* vp = V + ((long)b * Lk + (kvalid ? key : 0)) * ldv + head * DH + 16 * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = *reinterpret_cast<const float4*>(vp + 4 * i);
+            if (!kvalid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            vf[4 * i] = v.x; vf[4 * i + 1] = v.y; vf[4 * i + 2] = v.z; vf[4 * i + 3] = v.w;
+        }
+    }
+    float4 sq, sg;
+    float sl = 0.f;
+    auto fetch = [&](int t) {
+        const int qr = t * 32 + (tid >> 3), d4 = (tid & 7) << 2;
+        if (qr < Lq) {
+            sq = *reinterpret_cast<const float4*>(Qb + (long)qr * ldq + d4);
+            sg = *reinterpret_cast<const float4*>(Gb + (long)qr * lddo + d4);
+        } else {
+            sq = make_float4(0.f, 0.f, 0.f, 0.f);
+            sg = sq;
+        }
+        if (tid < 32) {
+            const int qq = t * 32 + tid;
+            sl = qq < Lq ? Lb[qq] * inv_scale : INFINITY;
+        } else if (tid < 64) {
+            const int qq = t * 32 + tid - 32;
+            sl = qq < Lq ? Db[qq] : 0.f;
+        }
+    };
+    auto stash = [&](int buf) {
+        *reinterpret_cast<float4*>(Qs(buf) + (tid >> 3) * QP + ((tid & 7) << 2)) = sq;
+        *reinterpret_cast<float4*>(Gs(buf) + (tid >> 3) * QP + ((tid & 7) << 2)) = sg;
+        if (tid < 32) Ls(buf)[tid] = sl;
+        else if (tid < 64) Ds(buf)[tid - 32] = sl;
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    // K fragment (B operand of S): lane holds K[key][16h .. 16h+15]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(Kt + (wave * 32 + l31) * QP + 16 * h + 4 * i);
+        kf[4 * i] = v.x; kf[4 * i + 1] = v.y; kf[4 * i + 2] = v.z; kf[4 * i + 3] = v.w;
+    }
+    f32x16 dk, dv;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
+
+    const int ntile = (Lq + 31) / 32;
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1;
+        const bool more = t + 1 < ntile;
+        if (more) fetch(t + 1);
+        const float* qs = Qs(cur);
+        const float* gs = Gs(cur);
+        // ---- S' = Q K^T - LSE/scale ; dP' = dO V^T - delta      (rows q, cols key)
+        f32x16 s, dp;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 l4 = *reinterpret_cast<const float4*>(Ls(cur) + 8 * g4 + 4 * h);
+            const float4 d4 = *reinterpret_cast<const float4*>(Ds(cur) + 8 * g4 + 4 * h);
+            s[4 * g4] = -l4.x; s[4 * g4 + 1] = -l4.y; s[4 * g4 + 2] = -l4.z; s[4 * g4 + 3] = -l4.w;
+            dp[4 * g4] = -d4.x; dp[4 * g4 + 1] = -d4.y; dp[4 * g4 + 2] = -d4.z; dp[4 * g4 + 3] = -d4.w;
+        }
+        {
+            float qf[16], gf[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 a = *reinterpret_cast<const float4*>(qs + l31 * QP + 16 * h + 4 * i);
+                const float4 g = *reinterpret_cast<const float4*>(gs + l31 * QP + 16 * h + 4 * i);
+                qf[4 * i] = a.x; qf[4 * i + 1] = a.y; qf[4 * i + 2] = a.z; qf[4 * i + 3] = a.w;
+                gf[4 * i] = g.x; gf[4 * i + 1] = g.y; gf[4 * i + 2] = g.z; gf[4 * i + 3] = g.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j], kf[j], s, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[j], vf[j], dp, 0, 0, 0);
+        }
+        // ---- P = exp2(c S'), dS = P * dP' * scale ; masked / out-of-range keys contribute nothing
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = kdead ? 0.f : __builtin_amdgcn_exp2f(s[e] * c);
+            s[e] = p;
+            dp[e] = p * dp[e] * scale;
+        }
+        // ---- dV += P^T dO ; dK += dS^T Q     (A = accumulator register e, B = row q(e,h) of the LDS tile)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int qr = acc_row(e, h);
+            dv = __builtin_amdgcn_mfma_f32_32x32x2f32(s[e], gs[qr * QP + l31], dv, 0, 0, 0);
+            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[e], qs[qr * QP + l31], dk, 0, 0, 0);
+        }
+        // ---- dQ tile = dS K : transpose dS through this wave's LDS patch
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dSs[acc_row(e, h) * QP + l31] = dp[e];
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        f32x16 dq;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+        {
+            float af[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 a = *reinterpret_cast<const float4*>(dSs + l31 * QP + 16 * h + 4 * i);
+                af[4 * i] = a.x; af[4 * i + 1] = a.y; af[4 * i + 2] = a.z; af[4 * i + 3] = a.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                dq = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], Kt[(wave * 32 + 16 * h + j) * QP + l31], dq, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int qr = t * 32 + acc_row(e, h);
+            if (qr < Lq) atomicAdd(dQ + ((long)b * Lq + qr) * lddq + head * DH + l31, dq[e]);
+        }
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+    }
+    // dK / dV: rows = this wave's keys, cols = channel on the lanes
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int kr = key_w0 + acc_row(e, h);
+        if (kr < Lk) {
+            dK[((long)b * Lk + kr) * lddk + head * DH + l31] = dk[e];
+            dV[((long)b * Lk + kr) * lddv + head * DH + l31] = dv[e];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                                const float* out, long ldo, const float* d_out, long lddo, const float* lse,
+                                const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq,
+                                float* dk, long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead,
+                                int head_dim, float scale, hipStream_t stream) {
+    SPOT_CHECK_ARG(q && k && v && out && d_out && lse && delta_ws && dq && dk && dv, "mha_bwd: null pointer");
+    SPOT_CHECK_ARG(head_dim == DH, "mha_bwd: head_dim=%d unsupported (this build handles 32)", head_dim);
+    SPOT_CHECK_ARG(B >= 0 && Lq > 0 && Lk > 0 && nhead > 0, "mha_bwd: bad shape B=%d Lq=%d Lk=%d heads=%d", B, Lq, Lk, nhead);
+    SPOT_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && lddo % 4 == 0 &&
+                       (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)d_out) & 15) == 0,
+                   "mha_bwd: operands must be 16-byte aligned with row strides that are multiples of 4");
+    SPOT_CHECK_ARG(B <= 65535 && nhead <= 65535, "mha_bwd: B and heads must fit a grid dimension");
+    if (B == 0) return SPOT_OK;
+    // dQ is accumulated atomically: clear its [B*Lq, nhead*32] window first
+    hipError_t e = hipMemset2DAsync(dq, (size_t)lddq * sizeof(float), 0, (size_t)nhead * DH * sizeof(float),
+                                    (size_t)B * Lq, stream);
+    if (e != hipSuccess) {
+        spot_set_error("mha_bwd: clearing dq failed: %s", hipGetErrorString(e));
+        return SPOT_ERR_LAUNCH;
+    }
+    const long total = (long)B * Lq * nhead;
+    mha_delta_kernel<<<(int)((total * 8 + 255) / 256), 256, 0, stream>>>(out, ldo, d_out, lddo, delta_ws, Lq, nhead, total);
+    SPOT_CHECK_LAUNCH("mha_bwd(delta)");
+    dim3 grid((Lk + 127) / 128, nhead, B);
+    mha_bwd_kernel<<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, d_out, lddo, lse, delta_ws, key_padding_mask, dq,
+                                             lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale);
+    SPOT_CHECK_LAUNCH("mha_bwd");
+    return SPOT_OK;
+}

@@ -1,0 +1,202 @@
+// LayerNorm over the channel dimension of token rows, forward and backward, and
+// the column sum that yields bias gradients.  HBM-bound row kernels: one wave
+// per token row, 16 bytes per lane per access.
+//
+// Reference: the nn.LayerNorm instances norm11..norm23 / norm1, norm2 /
+// decoder.norm of ltr/models/neck/transt_fusion.py:127-128,185-190,26.  The
+// residual sum that precedes each of them is produced by the GEMM epilogue
+// (gemm_f32.hip, `residual`), so this kernel reads the sum once.
+#include "common.h"
+#include "../../include/spot_hip.h"
+
+namespace {
+
+constexpr int MAXV = 4;   // float4 per lane: C <= 1024
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                                     int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C >> 2;
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float4* xp = reinterpret_cast<const float4*>(x + row * C);
+        float4 v[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int idx = lane + 64 * i;
+            v[i] = idx < nv ? xp[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mu = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            if (lane + 64 * i < nv) {
+                const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+                q += (a * a + b * b) + (c * c + d * d);
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / C + eps);
+        float4* yp = reinterpret_cast<float4*>(y + row * C);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx < nv) {
+                const float4 g = reinterpret_cast<const float4*>(gamma)[idx];
+                const float4 b = reinterpret_cast<const float4*>(beta)[idx];
+                yp[idx] = make_float4((v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y,
+                                      (v[i].z - mu) * rs * g.z + b.z, (v[i].w - mu) * rs * g.w + b.w);
+            }
+        }
+        if (lane == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;  dgamma += dy * xhat;  dbeta += dy
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, long rows,
+                                                     int C) {
+    __shared__ float4 red[2][4][64 * MAXV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C >> 2;
+    float4 gm[MAXV], ag[MAXV], ab[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        gm[i] = idx < nv ? reinterpret_cast<const float4*>(gamma)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[i] = ag[i];
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float4* xp = reinterpret_cast<const float4*>(x + row * C);
+        const float4* dp = reinterpret_cast<const float4*>(dy + row * C);
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[MAXV], g[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx < nv) {
+                const float4 xv = xp[idx], dv = dp[idx];
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                g[i] = make_float4(dv.x * gm[i].x, dv.y * gm[i].y, dv.z * gm[i].z, dv.w * gm[i].w);
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
+                ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+            } else {
+                xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                g[i] = xh[i];
+            }
+        }
+        const float c1 = wave_sum(s1) / C, c2 = wave_sum(s2) / C;
+        float4* op = reinterpret_cast<float4*>(dx + row * C);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx < nv)
+                op[idx] = make_float4(rs * (g[i].x - c1 - xh[i].x * c2), rs * (g[i].y - c1 - xh[i].y * c2),
+                                      rs * (g[i].z - c1 - xh[i].z * c2), rs * (g[i].w - c1 - xh[i].w * c2));
+        }
+    }
+    if (!dgamma && !dbeta) return;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        red[0][wave][lane + 64 * i] = ag[i];
+        red[1][wave][lane + 64 * i] = ab[i];
+    }
+    __syncthreads();
+    // 256 threads: thread t sums the 4 waves' partials of float4 slot t (and t+256..)
+    for (int idx = threadIdx.x; idx < nv; idx += 256) {
+        float4 a = red[0][0][idx], b = red[1][0][idx];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 a2 = red[0][w][idx], b2 = red[1][w][idx];
+            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+            b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+        }
+        if (dgamma) {
+            atomicAdd(dgamma + 4 * idx, a.x); atomicAdd(dgamma + 4 * idx + 1, a.y);
+            atomicAdd(dgamma + 4 * idx + 2, a.z); atomicAdd(dgamma + 4 * idx + 3, a.w);
+        }
+        if (dbeta) {
+            atomicAdd(dbeta + 4 * idx, b.x); atomicAdd(dbeta + 4 * idx + 1, b.y);
+            atomicAdd(dbeta + 4 * idx + 2, b.z); atomicAdd(dbeta + 4 * idx + 3, b.w);
+        }
+    }
+}
+
+// out[n] += sum_m x[m][n]; lanes along n (coalesced rows), waves and blocks along m.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, float* __restrict__ out,
+                                                     long rows, int N, long rows_per_block) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s0 = 0.f, s1 = 0.f;
+    if (n < N) {
+        long r = r0 + wave;
+        for (; r + 4 < r1; r += 8) {
+            s0 += x[r * ld + n];
+            s1 += x[(r + 4) * ld + n];
+        }
+        for (; r < r1; r += 4) s0 += x[r * ld + n];
+    }
+    red[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && n < N) atomicAdd(out + n, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+}
+
+}  // namespace
+
+extern "C" int spot_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                      float* rstd, long rows, int C, float eps, hipStream_t stream) {
+    SPOT_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null pointer");
+    SPOT_CHECK_ARG(rows >= 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXV, "layernorm_fwd: C=%d must be a multiple of 4, <= %d",
+                   C, 256 * MAXV);
+    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0,
+                   "layernorm_fwd: buffers must be 16-byte aligned");
+    if (rows == 0) return SPOT_OK;
+    long grid = (rows + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    ln_fwd_kernel<<<(int)grid, 256, 0, stream>>>(x, gamma, beta, y, mean, rstd, rows, C, eps);
+    SPOT_CHECK_LAUNCH("layernorm_fwd");
+    return SPOT_OK;
+}
+
+extern "C" int spot_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd,
+                                      const float* gamma, float* dx, float* dgamma, float* dbeta, long rows, int C,
+                                      hipStream_t stream) {
+    SPOT_CHECK_ARG(dy && x && mean && rstd && gamma && dx, "layernorm_bwd: null pointer");
+    SPOT_CHECK_ARG(rows >= 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXV, "layernorm_bwd: C=%d must be a multiple of 4, <= %d",
+                   C, 256 * MAXV);
+    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0,
+                   "layernorm_bwd: buffers must be 16-byte aligned");
+    if (rows == 0) return SPOT_OK;
+    long grid = (rows + 3) / 4;
+    if (grid > 1024) grid = 1024;
+    ln_bwd_kernel<<<(int)grid, 256, 0, stream>>>(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C);
+    SPOT_CHECK_LAUNCH("layernorm_bwd");
+    return SPOT_OK;
+}
+
+extern "C" int spot_colsum_f32(const float* x, long ld, float* out, long rows, int N, hipStream_t stream) {
+    SPOT_CHECK_ARG(x && out && rows >= 0 && N > 0, "colsum: bad arguments");
+    if (rows == 0) return SPOT_OK;
+    const int gx = (N + 63) / 64;
+    long gy = (rows + 255) / 256;
+    const long cap = 1024 / gx > 0 ? 1024 / gx : 1;
+    if (gy > cap) gy = cap;
+    const long rpb = (rows + gy - 1) / gy;
+    gy = (rows + rpb - 1) / rpb;
+    colsum_kernel<<<dim3(gx, (unsigned)gy), 256, 0, stream>>>(x, ld, out, rows, N, rpb);
+    SPOT_CHECK_LAUNCH("colsum");
+    return SPOT_OK;
+}

@@ -1,0 +1,90 @@
+"""ctypes binding of libspot_hip.so (the C ABI declared in include/spot_hip.h).
+
+The library is built in-tree by ``make -C spot_amd/csrc`` (hipcc, gfx950) or by
+``__graft_entry__.build()``.  There is no fallback: if the shared object is
+missing or a symbol cannot be resolved, importing the product ops fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspot_hip.so")
+
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
+
+
+class GemmDesc(C.Structure):
+    """Mirror of ``spot_gemm_desc``."""
+    _fields_ = [
+        ("A", vp), ("B", vp), ("C", vp),
+        ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
+        ("transA", i32), ("transB", i32),
+        ("lda", i64), ("ldb", i64), ("ldc", i64),
+        ("strideA", i64), ("strideB", i64), ("strideC", i64),
+        ("kseg", i32), ("segA", i64), ("segB", i64),
+        ("splitk", i32), ("alpha", f32), ("accumulate", i32),
+        ("bias", vp), ("rowbias", vp), ("rb_rows", i32), ("ldrb", i64),
+        ("relu", i32), ("mask", vp), ("ldmask", i64),
+        ("residual", vp), ("ldres", i64), ("strideRes", i64),
+    ]
+
+
+# name -> argument ctypes (all return int unless noted); the trailing hipStream_t is a void*
+SIGNATURES = {
+    "spot_preprocess_u8_f32": [vp, vp, C.POINTER(f32), C.POINTER(f32), vp, i32, i32, i32, i32, vp],
+    "spot_decode_teacher_f32": [vp, vp, vp, vp, f64, i32, i32, vp, vp, vp, vp, i32, i32, vp],
+    "spot_middleware_filter_f32": [vp, vp, vp, vp, vp, vp, i32, f32, vp, vp, vp, i32, vp],
+    "spot_decode_filter_f32": [vp, vp, vp, vp, f64, i32, i32, vp, vp, vp, vp, i32, f32,
+                               vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "spot_compact_indices": [vp, i32, vp, i32, vp, vp],
+    "spot_gather_rows": [vp, vp, vp, i32, i64, vp],
+    "spot_ema_lerp_f32": [vp, vp, i64, f64, vp],
+    "spot_ema_lerp_i64": [vp, vp, i32, f64, vp],
+    "spot_box_iou_pair_f32": [vp, vp, i32, vp, vp, vp, i32, vp],
+    "spot_box_giou_pair_bwd_f32": [vp, vp, vp, vp, vp, i32, vp],
+    "spot_xcorr_depthwise_f32": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "spot_groupdw_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "spot_gemm_f32": [C.POINTER(GemmDesc), vp],
+    "spot_colsum_f32": [vp, i64, vp, i64, i32, vp],
+    "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, vp],
+    "spot_mha_bwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64,
+                         i32, i32, i32, i32, i32, f32, vp],
+    "spot_layernorm_fwd_f32": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
+    "spot_layernorm_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "spot_amd: %s is missing. Build it with `make -C spot_amd/csrc` (hipcc, --offload-arch=gfx950); "
+            "there is no CPU fallback for the hot path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.spot_version.restype = i32
+    lib.spot_version.argtypes = []
+    lib.spot_last_error.restype = C.c_char_p
+    lib.spot_last_error.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale
+        fn.restype = i32
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().spot_last_error().decode("utf-8", "replace")
+        raise RuntimeError("spot_hip %s failed (%d): %s" % (what, rc, msg))
+
+
+def call(name, *args):
+    """Call a C-ABI entry point and raise on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    check(rc, name)

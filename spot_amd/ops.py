@@ -1,0 +1,502 @@
+"""Torch-facing wrappers of the C-ABI kernels (PyTorch supplies device memory and
+streams; every arithmetic step below runs in libspot_hip.so).
+
+Functional wrappers take/return torch CUDA tensors; the autograd Functions glue
+forward and backward kernels together so that the host modules (fusion.py,
+transt.py) read like the reference's nn.Modules.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib
+from .lib import GemmDesc
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk(t, dtype=torch.float32, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError("spot_amd: %s must live on the GPU (no CPU path exists)" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("spot_amd: %s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("spot_amd: %s must be contiguous" % name)
+    return t
+
+
+# ---------------------------------------------------------------------------
+# pre-input / pseudo-label path
+# ---------------------------------------------------------------------------
+def preprocess_u8(images, scale, mean, std):
+    """(clamp(u8 * scale[b], 0, 1) - mean) / std  ->  float32 [B,3,H,W]."""
+    _chk(images, torch.uint8, "images")
+    B, Cn, H, W = images.shape
+    out = torch.empty((B, Cn, H, W), dtype=torch.float32, device=images.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    lib.call("spot_preprocess_u8_f32", _p(images), _p(scale), m, s, _p(out), B, Cn, H, W, _st())
+    return out
+
+
+_WINDOWS = {}
+
+
+def hanning_window(feat_sz, device):
+    """outer(hanning, hanning) formed in float32, as transt_sparse_actor.py:65-68 does."""
+    key = (feat_sz, str(device))
+    if key not in _WINDOWS:
+        import numpy as np
+        h = torch.tensor(np.hanning(feat_sz), dtype=torch.float32)
+        _WINDOWS[key] = torch.outer(h, h).flatten().contiguous().to(device)
+    return _WINDOWS[key]
+
+
+def decode_teacher(pred_logits, pred_boxes, pred_ious, window_penalty, feat_sz, img_w, img_h):
+    B, L, _ = pred_logits.shape
+    dev = pred_logits.device
+    _chk(pred_logits), _chk(pred_boxes), _chk(pred_ious)
+    bbox = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    score = torch.empty((B,), dtype=torch.float32, device=dev)
+    conf = torch.empty((B,), dtype=torch.float32, device=dev)
+    idx = torch.empty((B,), dtype=torch.int32, device=dev)
+    lib.call("spot_decode_teacher_f32", _p(pred_logits), _p(pred_boxes), _p(pred_ious),
+             _p(hanning_window(feat_sz, dev)), float(window_penalty), int(img_w), int(img_h),
+             _p(bbox), _p(score), _p(conf), _p(idx), B, L, _st())
+    return bbox, score, conf, idx
+
+
+def middleware_filter(best_bbox, best_conf, unl_ext, unl_rf, aug_ext, aug_rf, search_sz, tau):
+    B = best_bbox.shape[0]
+    dev = best_bbox.device
+    for t in (best_bbox, best_conf, unl_ext, unl_rf, aug_ext, aug_rf):
+        _chk(t)
+    rec = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    aug = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    keep = torch.empty((B,), dtype=torch.uint8, device=dev)
+    lib.call("spot_middleware_filter_f32", _p(best_bbox), _p(best_conf), _p(unl_ext), _p(unl_rf), _p(aug_ext),
+             _p(aug_rf), int(search_sz), float(tau), _p(rec), _p(aug), _p(keep), B, _st())
+    return rec, aug, keep
+
+
+def decode_filter(pred_logits, pred_boxes, pred_ious, window_penalty, feat_sz, img_w, img_h,
+                  unl_ext, unl_rf, aug_ext, aug_rf, search_sz, tau):
+    """Fused decode + recover + keep mask + re-projection: one launch, no host sync."""
+    B, L, _ = pred_logits.shape
+    dev = pred_logits.device
+    for t in (pred_logits, pred_boxes, pred_ious, unl_ext, unl_rf, aug_ext, aug_rf):
+        _chk(t)
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    bbox, score, conf, rec, aug = f(B, 4), f(B), f(B), f(B, 4), f(B, 4)
+    idx = torch.empty((B,), dtype=torch.int32, device=dev)
+    keep = torch.empty((B,), dtype=torch.uint8, device=dev)
+    lib.call("spot_decode_filter_f32", _p(pred_logits), _p(pred_boxes), _p(pred_ious),
+             _p(hanning_window(feat_sz, dev)), float(window_penalty), int(img_w), int(img_h), _p(unl_ext),
+             _p(unl_rf), _p(aug_ext), _p(aug_rf), int(search_sz), float(tau), _p(bbox), _p(score), _p(conf),
+             _p(idx), _p(rec), _p(aug), _p(keep), B, L, _st())
+    return {"best_bbox": bbox, "best_score": score, "best_conf": conf, "best_idx": idx,
+            "bbox_recovered": rec, "aug_anno": aug, "aug_success": keep}
+
+
+def compact_indices(keep_u8, n_out):
+    _chk(keep_u8, torch.uint8, "keep")
+    dev = keep_u8.device
+    idx = torch.empty((n_out,), dtype=torch.int32, device=dev)
+    n = torch.empty((1,), dtype=torch.int32, device=dev)
+    lib.call("spot_compact_indices", _p(keep_u8), keep_u8.numel(), _p(idx), int(n_out), _p(n), _st())
+    return idx, n
+
+
+def gather_rows(src, idx):
+    """dst[r] = src[idx[r]] along dim 0 (any dtype)."""
+    if not src.is_contiguous():
+        raise RuntimeError("spot_amd: gather_rows source must be contiguous")
+    _chk(idx, torch.int32, "gather index")
+    n = idx.numel()
+    dst = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    row_bytes = src[0].numel() * src.element_size() if src.shape[0] > 0 else 0
+    if n and row_bytes:
+        lib.call("spot_gather_rows", _p(src), _p(dst), _p(idx), n, row_bytes, _st())
+    return dst
+
+
+def ema_lerp_(teacher_flat, student_flat, keep_rate):
+    _chk(teacher_flat), _chk(student_flat)
+    lib.call("spot_ema_lerp_f32", _p(teacher_flat), _p(student_flat), teacher_flat.numel(), float(keep_rate), _st())
+
+
+def ema_lerp_i64_(teacher_flat, student_flat, keep_rate):
+    _chk(teacher_flat, torch.int64), _chk(student_flat, torch.int64)
+    lib.call("spot_ema_lerp_i64", _p(teacher_flat), _p(student_flat), teacher_flat.numel(), float(keep_rate), _st())
+
+
+# ---------------------------------------------------------------------------
+# boxes
+# ---------------------------------------------------------------------------
+def box_iou_pair(b1, b2, cxcywh=False, want_giou=True):
+    _chk(b1), _chk(b2)
+    P = b1.shape[0]
+    f = lambda: torch.empty((P,), dtype=torch.float32, device=b1.device)
+    giou, iou, uni = (f() if want_giou else None), f(), f()
+    if P:
+        lib.call("spot_box_iou_pair_f32", _p(b1), _p(b2), int(cxcywh), _p(giou), _p(iou), _p(uni), P, _st())
+    return giou, iou, uni
+
+
+class GIoUPairFn(torch.autograd.Function):
+    """(giou, iou) of paired cxcywh boxes; gradient flows to the first set only."""
+
+    @staticmethod
+    def forward(ctx, src, tgt):
+        src, tgt = src.contiguous(), tgt.contiguous()
+        giou, iou, _ = box_iou_pair(src, tgt, cxcywh=True)
+        ctx.save_for_backward(src, tgt)
+        return giou, iou
+
+    @staticmethod
+    def backward(ctx, dg, di):
+        src, tgt = ctx.saved_tensors
+        P = src.shape[0]
+        out = torch.empty_like(src)
+        if P:
+            dg = dg.contiguous() if dg is not None else None
+            di = di.contiguous() if di is not None else None
+            lib.call("spot_box_giou_pair_bwd_f32", _p(src), _p(tgt), _p(dg), _p(di), _p(out), P, _st())
+        return out, None
+
+
+# ---------------------------------------------------------------------------
+# depthwise cross-correlation
+# ---------------------------------------------------------------------------
+def xcorr_depthwise(x, kernel):
+    """Drop-in for ocean_fusion.xcorr_depthwise (forward)."""
+    _chk(x), _chk(kernel)
+    B, Cn, hx, wx = x.shape
+    _, _, hz, wz = kernel.shape
+    out = torch.empty((B, Cn, hx - hz + 1, wx - wz + 1), dtype=torch.float32, device=x.device)
+    lib.call("spot_xcorr_depthwise_f32", _p(x), _p(kernel), _p(out), B * Cn, hx, wx, hz, wz, _st())
+    return out
+
+
+def groupdw(zs, xs, weight):
+    """Fused GroupDW.forward: softmax(weight)-weighted sum of three depthwise correlations."""
+    z11, z12, z21 = [_chk(t) for t in zs]
+    x11, x12, x21 = [_chk(t) for t in xs]
+    _chk(weight)
+    B, Cn, hx, wx = x11.shape
+    _, _, hz, wz = z11.shape
+    assert tuple(x12.shape[2:]) == (hx - 2, wx) and tuple(x21.shape[2:]) == (hx, wx - 2), "branch shapes"
+    assert tuple(z12.shape[2:]) == (hz - 2, wz) and tuple(z21.shape[2:]) == (hz, wz - 2), "branch shapes"
+    out = torch.empty((B, Cn, hx - hz + 1, wx - wz + 1), dtype=torch.float32, device=x11.device)
+    lib.call("spot_groupdw_f32", _p(x11), _p(x12), _p(x21), _p(z11), _p(z12), _p(z21), _p(weight), _p(out),
+             B * Cn, hx, wx, hz, wz, _st())
+    return out
+
+
+# ---------------------------------------------------------------------------
+# dense contractions
+# ---------------------------------------------------------------------------
+def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None, ldc=None, batch=1,
+         strideA=0, strideB=0, strideC=0, kseg=0, segA=0, segB=0, splitk=1, alpha=1.0, accumulate=False,
+         bias=None, rowbias=None, rb_rows=0, ldrb=0, relu=False, mask=None, ldmask=0, residual=None,
+         ldres=0, strideRes=0):
+    """Raw access to spot_gemm_f32; tensors are only used for their base pointers."""
+    d = GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
+    d.M, d.N, d.K, d.batch = M, N, K, batch
+    d.transA, d.transB = int(transA), int(transB)
+    d.lda = lda if lda is not None else (M if transA else K)
+    d.ldb = ldb if ldb is not None else (N if transB else K)
+    d.ldc = ldc if ldc is not None else N
+    d.strideA, d.strideB, d.strideC = strideA, strideB, strideC
+    d.kseg, d.segA, d.segB = kseg, segA, segB
+    d.splitk, d.alpha, d.accumulate = splitk, alpha, int(accumulate)
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.rowbias = rowbias.data_ptr() if rowbias is not None else None
+    d.rb_rows, d.ldrb = rb_rows, ldrb
+    d.relu = int(relu)
+    d.mask = mask.data_ptr() if mask is not None else None
+    d.ldmask = ldmask
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.ldres, d.strideRes = ldres, strideRes
+    lib.call("spot_gemm_f32", C.byref(d), _st())
+    return Cout
+
+
+def _view2d(t):
+    """[..., C] contiguous -> (2-D view, leading dim)."""
+    return t.reshape(-1, t.shape[-1])
+
+
+def linear_fwd(x2, W, bias=None, relu=False, residual=None, rowbias=None, out=None):
+    """y[M,N] = x2[M,K] W[N,K]^T + bias (+ rowbias[m % R]) -> relu -> + residual."""
+    M, K = x2.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+    gemm(x2, W, out, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=out.stride(0), bias=bias, relu=relu,
+         rowbias=rowbias, rb_rows=rowbias.shape[0] if rowbias is not None else 0,
+         ldrb=rowbias.stride(0) if rowbias is not None else 0,
+         residual=residual, ldres=residual.stride(0) if residual is not None else 0)
+    return out
+
+
+def linear_dgrad(dy2, W, mask=None, out=None, accumulate=False):
+    """dx[M,K] = dy2[M,N] W[N,K]  (optionally zeroed where mask <= 0, or added into out)."""
+    M, N = dy2.shape
+    K = W.shape[1]
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
+    gemm(dy2, W, out, M, K, N, transB=True, lda=dy2.stride(0), ldb=W.stride(0), ldc=out.stride(0), mask=mask,
+         ldmask=mask.stride(0) if mask is not None else 0, accumulate=accumulate)
+    return out
+
+
+def _splitk_for(rows_out, cols_out, k):
+    tiles = ((rows_out + 127) // 128) * ((cols_out + 127) // 128)
+    want = max(1, 512 // tiles)
+    return max(1, min(want, k // 256 if k >= 256 else 1))
+
+
+def linear_wgrad(dy2, x2, out=None, accumulate=False):
+    """dW[N,K] = dy2[M,N]^T x2[M,K], reduction over the M token rows split across workgroups."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    sk = _splitk_for(N, K, M)
+    if out is None:
+        out = torch.zeros((N, K), dtype=torch.float32, device=dy2.device)
+    elif not accumulate:
+        out.zero_()
+    gemm(dy2, x2, out, N, K, M, transA=True, transB=True, lda=dy2.stride(0), ldb=x2.stride(0), ldc=out.stride(0),
+         splitk=sk, accumulate=True)
+    return out
+
+
+def colsum(x2, out=None):
+    M, N = x2.shape
+    if out is None:
+        out = torch.zeros((N,), dtype=torch.float32, device=x2.device)
+    lib.call("spot_colsum_f32", _p(x2), x2.stride(0), _p(out), M, N, _st())
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear (+ fused ReLU) on [..., K] inputs."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu):
+        x2 = _view2d(x.contiguous())
+        y = linear_fwd(x2, W, b, relu=relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x2, W, y if relu else None)
+        ctx.has_bias = b is not None
+        return y.view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y = ctx.saved_tensors
+        dy2 = _view2d(dy.contiguous())
+        if ctx.relu:
+            dy2 = torch.where(y > 0, dy2, torch.zeros((), device=dy2.device))
+        dx = linear_dgrad(dy2, W) if ctx.needs_input_grad[0] else None
+        dW = linear_wgrad(dy2, x2) if ctx.needs_input_grad[1] else None
+        db = colsum(dy2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return (dx.view(*dy.shape[:-1], W.shape[1]) if dx is not None else None), dW, db, None
+
+
+def linear(x, W, b=None, relu=False):
+    return LinearFn.apply(x, W, b, relu)
+
+
+class FFNFn(torch.autograd.Function):
+    """z = x + linear2(relu(linear1(x)))  — the FFN sublayer with its residual
+    (transt_fusion.py:151-152,234-235,240-241), dropout-free."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2):
+        x2 = _view2d(x.contiguous())
+        h = linear_fwd(x2, W1, b1, relu=True)
+        z = linear_fwd(h, W2, b2, residual=x2)
+        ctx.save_for_backward(x2, h, W1, W2)
+        return z.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dz):
+        x2, h, W1, W2 = ctx.saved_tensors
+        dz2 = _view2d(dz.contiguous())
+        dh = linear_dgrad(dz2, W2, mask=h)                  # relu' folded into the epilogue
+        dW2 = linear_wgrad(dz2, h)
+        db2 = colsum(dz2)
+        dx = dz2.clone()
+        linear_dgrad(dh, W1, out=dx, accumulate=True)        # residual path + FFN path
+        dW1 = linear_wgrad(dh, x2)
+        db1 = colsum(dh)
+        return dx.view_as(dz), dW1, db1, dW2, db2
+
+
+# ---------------------------------------------------------------------------
+# LayerNorm
+# ---------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x2 = _view2d(x.contiguous())
+        rows, Cn = x2.shape
+        y = torch.empty_like(x2)
+        mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        lib.call("spot_layernorm_fwd_f32", _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, Cn,
+                 float(eps), _st())
+        ctx.save_for_backward(x2, mean, rstd, gamma)
+        return y.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, gamma = ctx.saved_tensors
+        dy2 = _view2d(dy.contiguous())
+        rows, Cn = x2.shape
+        dx = torch.empty_like(x2)
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(gamma)
+        lib.call("spot_layernorm_bwd_f32", _p(dy2), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dg), _p(db),
+                 rows, Cn, _st())
+        return dx.view_as(dy), dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+def layer_norm_infer(x, gamma, beta, eps=1e-5):
+    x2 = _view2d(x)
+    y = torch.empty_like(x2)
+    lib.call("spot_layernorm_fwd_f32", _p(x2), _p(gamma), _p(beta), _p(y), None, None, x2.shape[0], x2.shape[1],
+             float(eps), _st())
+    return y.view_as(x)
+
+
+# ---------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------
+def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, out=None):
+    dev = q.device
+    if out is None:
+        out = torch.empty((B * Lq, nhead * dh), dtype=torch.float32, device=dev)
+    lse = torch.empty((B, nhead, Lq), dtype=torch.float32, device=dev) if want_lse else None
+    lib.call("spot_mha_fwd_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), out.stride(0), _p(lse), _p(kpm),
+             B, Lq, Lk, nhead, dh, 1.0 / math.sqrt(dh), _st())
+    return out, lse
+
+
+def _pos_table(pos2, W, b):
+    """pos2[R,C] W[N,C]^T + b -> [R,N]: the additive term of (x + pos) W^T + b that does not depend on x."""
+    return linear_fwd(pos2, W, b)
+
+
+class MHAFn(torch.autograd.Function):
+    """z = residual + out_proj(MHA(q = xq + pos_q, k = xkv + pos_k, v = xkv)).
+
+    nn.MultiheadAttention as the fusion layers use it (transt_fusion.py:145-149,
+    212-214, 223-232) plus the residual add that follows it.  xq [B,Lq,C],
+    xkv [B,Lk,C]; pos_q [Rq,C] / pos_k [Rk,C] with R = L (shared by the batch) or
+    B*L; kpm [B,Lk] uint8 or None.  Positional terms enter as per-row bias
+    tables (pos W^T + b) added in the projection GEMM's epilogue, so x + pos is
+    never materialised.
+    """
+
+    @staticmethod
+    def forward(ctx, xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, residual, nhead, self_attn):
+        B, Lq, Cn = xq.shape
+        Lk = xkv.shape[1]
+        dh = Cn // nhead
+        xq2, xkv2 = _view2d(xq.contiguous()), _view2d(xkv.contiguous())
+        dev = xq.device
+        if self_attn:
+            R = pos_q.shape[0]
+            table = torch.empty((R, 3 * Cn), dtype=torch.float32, device=dev)
+            linear_fwd(pos_q, in_w[:2 * Cn], in_b[:2 * Cn], out=table[:, :2 * Cn])
+            table[:, 2 * Cn:] = in_b[2 * Cn:]
+            qkv = linear_fwd(xq2, in_w, None, rowbias=table)
+            q, k, v = qkv, qkv[:, Cn:], qkv[:, 2 * Cn:]
+            ldq = ldk = ldv = 3 * Cn
+            kv = None
+        else:
+            tq = _pos_table(pos_q, in_w[:Cn], in_b[:Cn])
+            tk = torch.empty((pos_k.shape[0], 2 * Cn), dtype=torch.float32, device=dev)
+            linear_fwd(pos_k, in_w[Cn:2 * Cn], in_b[Cn:2 * Cn], out=tk[:, :Cn])
+            tk[:, Cn:] = in_b[2 * Cn:]
+            qkv = linear_fwd(xq2, in_w[:Cn], None, rowbias=tq)
+            kv = linear_fwd(xkv2, in_w[Cn:], None, rowbias=tk)
+            q, k, v = qkv, kv, kv[:, Cn:]
+            ldq, ldk, ldv = Cn, 2 * Cn, 2 * Cn
+        need_grad = any(ctx.needs_input_grad)
+        attn, lse = mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, need_grad)
+        res2 = _view2d(residual.contiguous()) if residual is not None else None
+        z = linear_fwd(attn, out_w, out_b, residual=res2)
+        if need_grad:
+            ctx.save_for_backward(xq2, xkv2, pos_q, pos_k, in_w, out_w, qkv, kv, attn, lse, kpm)
+            ctx.dims = (B, Lq, Lk, Cn, nhead, dh, self_attn, residual is not None)
+        return z.view(B, Lq, Cn)
+
+    @staticmethod
+    def backward(ctx, dz):
+        xq2, xkv2, pos_q, pos_k, in_w, out_w, qkv, kv, attn, lse, kpm = ctx.saved_tensors
+        B, Lq, Lk, Cn, nhead, dh, self_attn, has_res = ctx.dims
+        dev = dz.device
+        dz2 = _view2d(dz.contiguous())
+        dattn = linear_dgrad(dz2, out_w)
+        d_out_w = linear_wgrad(dz2, attn)
+        d_out_b = colsum(dz2)
+        delta = torch.empty((B, nhead, Lq), dtype=torch.float32, device=dev)
+        scale = 1.0 / math.sqrt(dh)
+        d_in_w = torch.zeros_like(in_w)
+        d_in_b = torch.zeros((3 * Cn,), dtype=torch.float32, device=dev)
+        if self_attn:
+            dqkv = torch.empty_like(qkv)
+            lib.call("spot_mha_bwd_f32", _p(qkv), 3 * Cn, _p(qkv[:, Cn:]), 3 * Cn, _p(qkv[:, 2 * Cn:]), 3 * Cn,
+                     _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
+                     _p(dqkv), 3 * Cn, _p(dqkv[:, Cn:]), 3 * Cn, _p(dqkv[:, 2 * Cn:]), 3 * Cn,
+                     B, Lq, Lk, nhead, dh, scale, _st())
+            dxq = linear_dgrad(dqkv, in_w)
+            dxkv = None
+            linear_wgrad(dqkv, xq2, out=d_in_w, accumulate=True)
+            colsum(dqkv, out=d_in_b)
+            # (x + pos) W^T: the pos part of dW is (sum over clips of dq|dk)^T pos
+            R = pos_q.shape[0]
+            dqk_sum = dqkv[:, :2 * Cn].reshape(-1, R, 2 * Cn).sum(0) if R != dqkv.shape[0] else dqkv[:, :2 * Cn]
+            linear_wgrad(dqk_sum.contiguous(), pos_q, out=d_in_w[:2 * Cn], accumulate=True)
+        else:
+            dq = torch.empty_like(qkv)
+            dkv = torch.empty_like(kv)
+            lib.call("spot_mha_bwd_f32", _p(qkv), Cn, _p(kv), 2 * Cn, _p(kv[:, Cn:]), 2 * Cn,
+                     _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
+                     _p(dq), Cn, _p(dkv), 2 * Cn, _p(dkv[:, Cn:]), 2 * Cn,
+                     B, Lq, Lk, nhead, dh, scale, _st())
+            dxq = linear_dgrad(dq, in_w[:Cn])
+            dxkv = linear_dgrad(dkv, in_w[Cn:])
+            linear_wgrad(dq, xq2, out=d_in_w[:Cn], accumulate=True)
+            linear_wgrad(dkv, xkv2, out=d_in_w[Cn:], accumulate=True)
+            colsum(dq, out=d_in_b[:Cn])
+            colsum(dkv, out=d_in_b[Cn:])
+            Rq, Rk = pos_q.shape[0], pos_k.shape[0]
+            dq_sum = dq.reshape(-1, Rq, Cn).sum(0) if Rq != dq.shape[0] else dq
+            dk_sum = dkv[:, :Cn].reshape(-1, Rk, Cn).sum(0) if Rk != dkv.shape[0] else dkv[:, :Cn]
+            linear_wgrad(dq_sum.contiguous(), pos_q, out=d_in_w[:Cn], accumulate=True)
+            linear_wgrad(dk_sum.contiguous(), pos_k, out=d_in_w[Cn:2 * Cn], accumulate=True)
+        dres = dz if has_res else None
+        if self_attn:
+            # xq and xkv are the same tensor: hand the whole gradient to xq
+            return (dxq.view(B, Lq, Cn), None, None, None, d_in_w, d_in_b, d_out_w, d_out_b, None, dres, None, None)
+        return (dxq.view(B, Lq, Cn), dxkv.view(B, Lk, Cn), None, None, d_in_w, d_in_b, d_out_w, d_out_b, None,
+                dres, None, None)
+
+
+def mha_block(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, residual, nhead, self_attn):
+    return MHAFn.apply(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, residual, nhead, self_attn)

@@ -1,0 +1,358 @@
+"""Parity of each HIP kernel (called through the C ABI) against the CPU oracle and
+the golden vectors produced by the reference.  Needs a real MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spot_oracle as O
+from spot_amd.detinit import det_array, det_input
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def G(a):
+    return T(a).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from spot_amd import ops as _ops, lib
+    lib.load()
+    return _ops
+
+
+# --------------------------------------------------------------------------- pseudo-label path
+def test_decode_filter_golden(ops, golden):
+    g = golden("g6_decode")
+    lg, bx, io = G(g["logits"]), G(g["boxes"]), G(g["ious"].reshape(16, 1024))
+    bbox, score, conf, idx = ops.decode_teacher(lg, bx, io, 0.40, 32, 256, 256)
+    dec = O.decode_teacher(T(g["logits"]), T(g["boxes"]), T(g["ious"]), 0.40, 32, 256, 256)
+    assert np.array_equal(idx.cpu().numpy(), dec["best_idx"].numpy().astype(np.int32))
+    np.testing.assert_allclose(bbox.cpu().numpy(), g["best_bbox"], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(score.cpu().numpy(), g["best_score"], rtol=1e-6)
+    # middleware on the golden's confidences (tau-eps, tau, tau+eps hand-placed at 3..5)
+    conf_g = G(g["best_conf"])
+    rec, aug, keep = ops.middleware_filter(G(g["best_bbox"]), conf_g, G(g["mid_unlabeled_box_extract"].reshape(16, 4)),
+                                           G(g["mid_unlabeled_resize_factors"]),
+                                           G(g["mid_aug_box_extract"].reshape(16, 4)),
+                                           G(g["mid_aug_resize_factors"]), 256, 0.85)
+    assert np.array_equal(keep.cpu().numpy().astype(bool), g["aug_success"])
+    np.testing.assert_allclose(aug.cpu().numpy(), g["aug_anno"], rtol=1e-6, atol=1e-4)
+    # fused variant must agree with the two-call variant bit for bit
+    fused = ops.decode_filter(lg, bx, io, 0.40, 32, 256, 256, G(g["mid_unlabeled_box_extract"].reshape(16, 4)),
+                              G(g["mid_unlabeled_resize_factors"]), G(g["mid_aug_box_extract"].reshape(16, 4)),
+                              G(g["mid_aug_resize_factors"]), 256, 0.85)
+    rec2, aug2, keep2 = ops.middleware_filter(bbox, conf, G(g["mid_unlabeled_box_extract"].reshape(16, 4)),
+                                              G(g["mid_unlabeled_resize_factors"]),
+                                              G(g["mid_aug_box_extract"].reshape(16, 4)),
+                                              G(g["mid_aug_resize_factors"]), 256, 0.85)
+    assert torch.equal(fused["aug_anno"], aug2) and torch.equal(fused["aug_success"], keep2)
+    assert torch.equal(fused["best_bbox"], bbox) and torch.equal(fused["bbox_recovered"], rec2)
+
+
+def test_decode_random_vs_oracle(ops):
+    B, L = 128, 1024
+    lg = det_input("lg", (B, L, 2), 5, -6, 6)
+    bx = det_input("bx", (B, L, 4), 5, 0, 1)
+    io = det_input("io", (B, L, 1), 5, 0, 1)
+    bbox, score, conf, idx = ops.decode_teacher(G(lg), G(bx), G(io.reshape(B, L)), 0.40, 32, 256, 256)
+    dec = O.decode_teacher(T(lg), T(bx), T(io), 0.40, 32, 256, 256)
+    # exclude clips whose top-2 blended scores are closer than fp32 rounding of exp()
+    top2 = torch.topk(dec["score_map"], 2, dim=1).values
+    ok = ((top2[:, 0] - top2[:, 1]) > 1e-6).numpy()
+    assert ok.sum() > B * 0.9
+    assert np.array_equal(idx.cpu().numpy()[ok], dec["best_idx"].numpy().astype(np.int32)[ok])
+    np.testing.assert_allclose(bbox.cpu().numpy()[ok], dec["best_bbox"].numpy()[ok], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(conf.cpu().numpy()[ok], dec["best_conf"].numpy()[ok], rtol=0, atol=0)
+    np.testing.assert_allclose(score.cpu().numpy(), dec["best_score"].numpy(), rtol=2e-6)
+
+
+def test_decode_ragged_L(ops):
+    # token counts that are not a multiple of the workgroup size, B = 1 and B = 0
+    for B, n in ((1, 5), (3, 9), (2, 20)):
+        L = n * n
+        lg = det_input("lg", (B, L, 2), 6, -3, 3)
+        bx = det_input("bx", (B, L, 4), 6, 0, 1)
+        io = det_input("io", (B, L, 1), 6, 0, 1)
+        bbox, score, conf, idx = ops.decode_teacher(G(lg), G(bx), G(io.reshape(B, L)), 0.3, n, 64, 48)
+        dec = O.decode_teacher(T(lg), T(bx), T(io), 0.3, n, 64, 48)
+        assert np.array_equal(idx.cpu().numpy(), dec["best_idx"].numpy().astype(np.int32))
+        np.testing.assert_allclose(bbox.cpu().numpy(), dec["best_bbox"].numpy(), rtol=1e-6, atol=1e-5)
+    e = torch.empty((0, 16, 2), device=DEV)
+    out = ops.decode_teacher(e, torch.empty((0, 16, 4), device=DEV), torch.empty((0, 16), device=DEV), 0.4, 4, 8, 8)
+    assert out[0].shape == (0, 4)
+
+
+def test_compaction_golden(ops, golden):
+    g = golden("g7_compaction")
+    for n in [k[5:] for k in g.files if k.startswith("mask_")]:
+        keep = G(g["mask_" + n].astype(np.uint8))
+        idx, nk = ops.compact_indices(keep, keep.numel())
+        assert np.array_equal(idx.cpu().numpy(), g["idx_" + n].astype(np.int32)), n
+        assert int(nk.item()) == int(g["mask_" + n].sum())
+    idx, nk = ops.compact_indices(torch.zeros(24, dtype=torch.uint8, device=DEV), 24)
+    assert int(nk.item()) == 0 and bool((idx == -1).all())
+    # large ragged batch, different output size
+    keep = det_input("k", (3001,), 9, 0, 1) > 0.7
+    idx, nk = ops.compact_indices(G(keep.astype(np.uint8)), 4096)
+    ref = O.compact_indices(keep, 4096)
+    assert np.array_equal(idx.cpu().numpy(), ref.astype(np.int32))
+
+
+def test_gather_rows(ops):
+    src = G(det_input("src", (24, 3, 16, 16), 3, 0, 256, np.uint8))
+    idx = torch.tensor([5, 0, 23, 5, 7], dtype=torch.int32, device=DEV)
+    assert torch.equal(ops.gather_rows(src, idx), src[idx.long()])
+    srcf = G(det_input("srcf", (24, 3), 3, 0, 1))       # 12-byte rows: byte path
+    assert torch.equal(ops.gather_rows(srcf, idx), srcf[idx.long()])
+
+
+def test_boxes_golden(ops, golden):
+    g = golden("g8_boxes")
+    b1, b2 = G(g["b1"]), G(g["b2"])
+    giou, iou, uni = ops.box_iou_pair(b1, b2, cxcywh=True)
+    np.testing.assert_allclose(giou.cpu().numpy(), g["giou"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(iou.cpu().numpy(), g["iou"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(uni.cpu().numpy(), g["union"], rtol=1e-6)
+    x1, x2 = O.box_cxcywh_to_xyxy(T(g["b1"])), O.box_cxcywh_to_xyxy(T(g["b2"]))
+    giou2, iou2, _ = ops.box_iou_pair(x1.to(DEV).contiguous(), x2.to(DEV).contiguous(), cxcywh=False)
+    np.testing.assert_allclose(giou2.cpu().numpy(), g["giou"], rtol=1e-6, atol=1e-7)
+    # backward of sum(1 - giou) w.r.t. the first box set
+    s = b1.clone().requires_grad_()
+    gi, _ = ops.GIoUPairFn.apply(s, b2)
+    (1 - gi).sum().backward()
+    np.testing.assert_allclose(s.grad.cpu().numpy(), g["dgiou_db1"], rtol=1e-4, atol=1e-5)
+
+
+def test_xcorr_golden(ops, golden):
+    g = golden("g12_xcorr")
+    for tag in ("ocean255", "cfg5"):
+        B, C, hx, hz = [int(v) for v in g["dims_" + tag]]
+        shp_x = [(hx - 2, hx - 2), (hx - 4, hx - 2), (hx - 2, hx - 4)]
+        shp_z = [(hz - 2, hz - 2), (hz - 4, hz - 2), (hz - 2, hz - 4)]
+        xs = [G(det_input("x%d%s" % (i, tag), (B, C) + s, 71, -1, 1)) for i, s in enumerate(shp_x)]
+        zs = [G(det_input("z%d%s" % (i, tag), (B, C) + s, 71, -1, 1)) for i, s in enumerate(shp_z)]
+        re11 = ops.xcorr_depthwise(xs[0], zs[0])
+        np.testing.assert_allclose(re11.cpu().numpy(), g["re11_" + tag], rtol=1e-4, atol=1e-5)
+        s = ops.groupdw(zs, xs, G(np.asarray(g["weight"], np.float32)))
+        np.testing.assert_allclose(s.cpu().numpy(), g["groupdw_" + tag], rtol=1e-4, atol=1e-5)
+
+
+def test_xcorr_odd_shapes_vs_oracle(ops):
+    # generic template sizes (runtime path), single plane, planes whose byte offset is not 16-aligned
+    for (B, C, hx, wx, hz, wz) in ((1, 1, 9, 7, 3, 2), (2, 3, 31, 31, 7, 7), (1, 5, 12, 17, 1, 1), (3, 2, 8, 8, 8, 8)):
+        x = det_input("x", (B, C, hx, wx), 7, -1, 1)
+        z = det_input("z", (B, C, hz, wz), 7, -1, 1)
+        out = ops.xcorr_depthwise(G(x), G(z)).cpu().numpy()
+        np.testing.assert_allclose(out, O.xcorr_depthwise(x, z), rtol=1e-4, atol=1e-5)
+
+
+def test_preprocess_golden(ops, golden):
+    g = golden("g14_pre_pos")
+    img = det_input("img", (2, 3, 16, 16), 91, 0, 256, np.uint8)
+    out = ops.preprocess_u8(G(img), None, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    np.testing.assert_allclose(out.cpu().numpy(), g["img_out"], rtol=1e-6, atol=1e-6)
+    # brightness jitter path, values that clamp
+    img = det_input("img2", (4, 3, 32, 32), 92, 0, 256, np.uint8)
+    br = np.array([0.8, 1.0, 1.2, 1.19], np.float32)
+    out = ops.preprocess_u8(G(img), G(br / np.float32(255.0)), [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    ref, _ = O.preprocess(T(img), torch.zeros(4, 3), [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], T(br))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_ema(ops, golden):
+    n = 100003
+    t = det_input("t", (n,), 1, -1, 1)
+    s = det_input("s", (n,), 2, -1, 1)
+    tg = G(t)
+    ops.ema_lerp_(tg, G(s), 0.998)
+    ref = T(s) * (1 - 0.998) + T(t) * 0.998
+    assert torch.equal(tg.cpu(), ref)
+    ti = torch.tensor([100, 7, 0], dtype=torch.int64, device=DEV)
+    si = torch.tensor([7, 100, 5], dtype=torch.int64, device=DEV)
+    ops.ema_lerp_i64_(ti, si, 0.998)
+    ref = (si.cpu() * (1 - 0.998) + torch.tensor([100, 7, 0]) * 0.998).to(torch.int64)
+    assert torch.equal(ti.cpu(), ref)
+
+
+# --------------------------------------------------------------------------- dense kernels
+def _ref_gemm(A, B, transA, transB):
+    a = A.double().t() if transA else A.double()
+    b = B.double() if transB else B.double().t()
+    return a @ b
+
+
+@pytest.mark.parametrize("transA", [False, True])
+@pytest.mark.parametrize("transB", [False, True])
+def test_gemm_layouts(ops, transA, transB):
+    for (M, N, K) in ((256, 256, 256), (384, 130, 96), (100, 2, 256), (37, 53, 19), (512, 768, 64)):
+        A = det_input("A", (K, M) if transA else (M, K), 1, -1, 1)
+        B = det_input("B", (K, N) if transB else (N, K), 2, -1, 1)
+        Cg = torch.empty((M, N), device=DEV)
+        ops.gemm(G(A), G(B), Cg, M, N, K, transA=transA, transB=transB)
+        ref = _ref_gemm(T(A), T(B), transA, transB)
+        np.testing.assert_allclose(Cg.cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * math.sqrt(K))
+
+
+def test_gemm_epilogues_splitk_segments(ops):
+    M, N, K = 512, 256, 384
+    A, B = det_input("A", (M, K), 3, -1, 1), det_input("B", (N, K), 4, -1, 1)
+    bias, rb = det_input("b", (N,), 5, -1, 1), det_input("rb", (128, N), 6, -1, 1)
+    res = det_input("res", (M, N), 7, -1, 1)
+    base = T(A).double() @ T(B).double().t()
+    Cg = torch.empty((M, N), device=DEV)
+    ops.gemm(G(A), G(B), Cg, M, N, K, bias=G(bias), rowbias=G(rb), rb_rows=128, ldrb=N, relu=True, residual=G(res),
+             ldres=N)
+    ref = torch.relu(base + T(bias).double() + T(rb).double().repeat(M // 128, 1)) + T(res).double()
+    np.testing.assert_allclose(Cg.cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+    mask = det_input("mask", (M, N), 8, -1, 1)
+    ops.gemm(G(A), G(B), Cg, M, N, K, mask=G(mask), ldmask=N, alpha=0.5)
+    ref = torch.where(T(mask) > 0, 0.5 * base, torch.zeros((), dtype=torch.float64))
+    np.testing.assert_allclose(Cg.cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+    # split-K accumulate
+    Cg.zero_()
+    ops.gemm(G(A), G(B), Cg, M, N, K, splitk=4, accumulate=True)
+    np.testing.assert_allclose(Cg.cpu().double().numpy(), base.numpy(), rtol=1e-5, atol=1e-4)
+    # batched
+    Ab, Bb = det_input("Ab", (3, 64, 32), 9, -1, 1), det_input("Bb", (3, 48, 32), 10, -1, 1)
+    Cb = torch.empty((3, 64, 48), device=DEV)
+    ops.gemm(G(Ab), G(Bb), Cb, 64, 48, 32, batch=3, strideA=64 * 32, strideB=48 * 32, strideC=64 * 48)
+    np.testing.assert_allclose(Cb.cpu().numpy(), (T(Ab) @ T(Bb).transpose(1, 2)).numpy(), rtol=1e-5, atol=1e-5)
+    # segmented K: sum over 4 slabs of a [4, K=64, M=96] x [4, N=40, K=64] pair (NCHW-style reduction)
+    As, Bs = det_input("As", (4, 64, 96), 11, -1, 1), det_input("Bs", (4, 40, 64), 12, -1, 1)
+    Cs = torch.empty((96, 40), device=DEV)
+    ops.gemm(G(As), G(Bs), Cs, 96, 40, 256, transA=True, lda=96, ldb=64, kseg=64, segA=64 * 96, segB=40 * 64)
+    ref = sum(T(As[i]).double().t() @ T(Bs[i]).double().t() for i in range(4))
+    np.testing.assert_allclose(Cs.cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_layernorm(ops):
+    for rows, C in ((1000, 256), (37, 64), (8, 1024)):
+        x = det_input("x", (rows, C), 1, -2, 2)
+        gm, bt = det_input("g", (C,), 2, 0.5, 1.5), det_input("b", (C,), 3, -1, 1)
+        dy = det_input("dy", (rows, C), 4, -1, 1)
+        xg, gg, bg = G(x).requires_grad_(), G(gm).requires_grad_(), G(bt).requires_grad_()
+        y = ops.layer_norm(xg, gg, bg)
+        (y * G(dy)).sum().backward()
+        xc, gc, bc = T(x).double().requires_grad_(), T(gm).double().requires_grad_(), T(bt).double().requires_grad_()
+        yc = torch.nn.functional.layer_norm(xc, (C,), gc, bc, 1e-5)
+        (yc * T(dy).double()).sum().backward()
+        np.testing.assert_allclose(y.detach().cpu().numpy(), yc.detach().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(gg.grad.cpu().numpy(), gc.grad.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(bg.grad.cpu().numpy(), bc.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def _ref_attn(q, k, v, kpm, nhead):
+    B, Lq, C = q.shape
+    dh = C // nhead
+    qh = q.view(B, Lq, nhead, dh).transpose(1, 2) / math.sqrt(dh)
+    kh = k.view(B, -1, nhead, dh).transpose(1, 2)
+    vh = v.view(B, -1, nhead, dh).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2)
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Lq, C)
+
+
+@pytest.mark.parametrize("Lq,Lk", [(256, 256), (1024, 256), (256, 1024), (16, 64), (50, 77)])
+def test_mha_core_fwd_bwd(ops, Lq, Lk):
+    from spot_amd import lib as L
+    B, nh, dh = 2, 4, 32
+    C = nh * dh
+    q, k, v = (det_input(n, (B, L_, C), 1, -2, 2) for n, L_ in (("q", Lq), ("k", Lk), ("v", Lk)))
+    do = det_input("do", (B, Lq, C), 2, -1, 1)
+    kpm = np.zeros((B, Lk), bool)
+    kpm[1, Lk // 2:Lk // 2 + 5] = True
+    kpm[1, -3:] = True
+    qg, kg, vg, kp = G(q).view(-1, C), G(k).view(-1, C), G(v).view(-1, C), G(kpm.astype(np.uint8))
+    out, lse = ops.mha_core_fwd(qg, C, kg, C, vg, C, B, Lq, Lk, nh, dh, kp, True)
+    qc, kc, vc = (T(a).double().requires_grad_() for a in (q, k, v))
+    ref = _ref_attn(qc, kc, vc, T(kpm), nh)
+    np.testing.assert_allclose(out.view(B, Lq, C).cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    (ref * T(do).double()).sum().backward()
+    dq, dk, dv = torch.empty_like(qg), torch.empty_like(kg), torch.empty_like(vg)
+    delta = torch.empty((B, nh, Lq), device=DEV)
+    dog = G(do).view(-1, C)
+    P = ops._p
+    L.call("spot_mha_bwd_f32", P(qg), C, P(kg), C, P(vg), C, P(out), C, P(dog), C, P(lse), P(kp), P(delta),
+           P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), ops._st())
+    np.testing.assert_allclose(dq.view(B, Lq, C).cpu().numpy(), qc.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dk.view(B, Lk, C).cpu().numpy(), kc.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dv.view(B, Lk, C).cpu().numpy(), vc.grad.numpy(), rtol=2e-4, atol=2e-5)
+
+
+# --------------------------------------------------------------------------- fusion network
+def _load_det(module, seed):
+    from spot_amd.detinit import det_fill_
+    det_fill_(module, seed)
+    return module.to(DEV)
+
+
+def test_mha_block_golden(ops, golden):
+    """Full attention block (projections + core) against nn.MultiheadAttention outputs of the reference run."""
+    from spot_amd.fusion import _AttentionParams
+    g = golden("g3_mha")
+    d, nh, B = 256, 8, 2
+    att = _load_det(_AttentionParams(d, nh), 13)
+    for tag, (Lq, Lk) in {"tt": (256, 256), "ss": (1024, 1024), "ts": (256, 1024), "st": (1024, 256)}.items():
+        a = lambda n, L_: G(det_input(n + tag, (L_, B, d), 13, -1, 1)).transpose(0, 1).contiguous()
+        xq, pq = a("xq", Lq), a("pq", Lq)
+        self_attn = tag in ("tt", "ss")
+        xk, pk = (xq, pq) if self_attn else (a("xk", Lk), a("pk", Lk))
+        kpm = G(g["kpm_" + tag].astype(np.uint8))
+        with torch.no_grad():
+            o = att(xq, xk, pq.reshape(-1, d), pk.reshape(-1, d), kpm, None, self_attn)
+        o = o.transpose(0, 1).cpu().numpy()
+        np.testing.assert_allclose(o[::8], g["out_" + tag], rtol=1e-3, atol=2e-5)
+        np.testing.assert_allclose(np.linalg.norm(o, axis=-1), g["rownorm_" + tag], rtol=1e-4)
+
+
+def test_fusion_layer_fwd_bwd_golden(ops, golden):
+    from spot_amd.fusion import FeatureFusionLayer
+    g = golden("g4_layer_bwd")
+    d, nh, ff, B, Lt, Ls = [int(v) for v in g["dims"]]
+    layer = _load_det(FeatureFusionLayer(d, nh, ff, 0.0), 14).train()
+    a = lambda n, L_: G(det_input(n, (L_, B, d), 14, -1, 1)).transpose(0, 1).contiguous()
+    s1, s2 = a("s1", Lt).requires_grad_(), a("s2", Ls).requires_grad_()
+    # per-sample positional rows (R = B*L), as in the golden
+    o1, o2 = layer(s1, s2, None, None, a("p1", Lt).reshape(-1, d), a("p2", Ls).reshape(-1, d))
+    ((o1 * a("g1", Lt)).sum() + (o2 * a("g2", Ls)).sum()).backward()
+    np.testing.assert_allclose(o1.detach().transpose(0, 1).cpu().numpy(), g["out1"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(o2.detach().transpose(0, 1).cpu().numpy(), g["out2"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(s1.grad.transpose(0, 1).cpu().numpy(), g["ds1"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(s2.grad.transpose(0, 1).cpu().numpy(), g["ds2"], rtol=2e-3, atol=2e-4)
+    for k, p in layer.named_parameters():
+        ref = g["grad." + k]
+        tol = 2e-3 * max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=tol, err_msg=k)
+
+
+def test_fusion_network_golden(ops, golden):
+    from spot_amd.fusion import FeatureFusionNetwork
+    g = golden("g1_fusion_tiny")
+    d, nh, nl, ff, B, ht, hs = [int(v) for v in g["dims"]]
+    net = _load_det(FeatureFusionNetwork(d, nh, nl, ff, 0.1), 11).eval()
+    a = lambda n, s: G(det_input(n, s, 11, -1, 1))
+    with torch.no_grad():
+        out = net(a("src_temp", (B, d, ht, ht)), G(g["mask_temp"]), a("src_search", (B, d, hs, hs)),
+                  G(g["mask_search"]), a("pos_temp", (B, d, ht, ht)), a("pos_search", (B, d, hs, hs)))
+    np.testing.assert_allclose(out.cpu().numpy(), g["hs"], rtol=1e-3, atol=1e-4)
+    g = golden("g2_fusion_full")
+    d, nh, nl, ff, B, ht, hs = [int(v) for v in g["dims"]]
+    net = _load_det(FeatureFusionNetwork(d, nh, nl, ff, 0.1), 12).eval()
+    a = lambda n, s: G(det_input(n, s, 12, -1, 1))
+    z = lambda *s: torch.zeros(*s, dtype=torch.bool, device=DEV)
+    with torch.no_grad():
+        out = net(a("src_temp", (B, d, ht, ht)), z(B, ht, ht), a("src_search", (B, d, hs, hs)), z(B, hs, hs),
+                  a("pos_temp", (B, d, ht, ht)), a("pos_search", (B, d, hs, hs))).cpu().numpy()
+    np.testing.assert_allclose(out[:, :, ::16, ::8], g["hs_slice"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(np.linalg.norm(out, axis=-1), g["hs_rownorm"], rtol=1e-4)
