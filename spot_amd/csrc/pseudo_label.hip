@@ -14,6 +14,10 @@
 #include "common.h"
 #include "../../include/spot_hip.h"
 
+// The reference evaluates these expressions as separate rounded multiplies and adds.  HIP's
+// __fmul_rn/__fadd_rn are plain operators and hipcc fuses them by default, so this file is
+// compiled with -ffp-contract=off (see the Makefile); explicit fmaf() calls stay fused.
+
 namespace {
 
 struct Best {
@@ -178,9 +182,9 @@ extern "C" int spot_decode_teacher_f32(const float* pred_logits, const float* pr
                                        float* best_bbox, float* best_score, float* best_conf, int* best_idx,
                                        int B, int L, hipStream_t stream) {
     SPOT_CHECK_ARG(B >= 0 && L > 0, "decode_teacher: bad B=%d L=%d", B, L);
+    if (B == 0) return SPOT_OK;
     SPOT_CHECK_ARG(pred_logits && pred_boxes && pred_ious && window && best_bbox && best_score && best_conf &&
                        best_idx, "decode_teacher: null pointer");
-    if (B == 0) return SPOT_OK;
     decode_filter_kernel<true, false><<<B, 256, 0, stream>>>(
         pred_logits, pred_boxes, pred_ious, window, (float)window_penalty, (float)(1.0 - window_penalty),
         (float)img_w, (float)img_h, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, best_bbox, best_score,
@@ -195,10 +199,10 @@ extern "C" int spot_middleware_filter_f32(const float* best_bbox, const float* b
                                           int search_sz, float confidence_threshold, float* bbox_recovered,
                                           float* aug_anno, unsigned char* aug_success, int B, hipStream_t stream) {
     SPOT_CHECK_ARG(B >= 0, "middleware_filter: bad B=%d", B);
+    if (B == 0) return SPOT_OK;
     SPOT_CHECK_ARG(best_bbox && best_conf && unlabeled_box_extract && unlabeled_resize_factors &&
                        aug_box_extract && aug_resize_factors && bbox_recovered && aug_anno && aug_success,
                    "middleware_filter: null pointer");
-    if (B == 0) return SPOT_OK;
     decode_filter_kernel<false, true><<<B, 64, 0, stream>>>(
         nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, unlabeled_box_extract, unlabeled_resize_factors,
         aug_box_extract, aug_resize_factors, (float)((search_sz - 1) / 2.0), confidence_threshold,
@@ -216,11 +220,11 @@ extern "C" int spot_decode_filter_f32(const float* pred_logits, const float* pre
                                       float* best_conf, int* best_idx, float* bbox_recovered, float* aug_anno,
                                       unsigned char* aug_success, int B, int L, hipStream_t stream) {
     SPOT_CHECK_ARG(B >= 0 && L > 0, "decode_filter: bad B=%d L=%d", B, L);
+    if (B == 0) return SPOT_OK;
     SPOT_CHECK_ARG(pred_logits && pred_boxes && pred_ious && window && unlabeled_box_extract &&
                        unlabeled_resize_factors && aug_box_extract && aug_resize_factors && best_bbox &&
                        best_score && best_conf && best_idx && bbox_recovered && aug_anno && aug_success,
                    "decode_filter: null pointer");
-    if (B == 0) return SPOT_OK;
     decode_filter_kernel<true, true><<<B, 256, 0, stream>>>(
         pred_logits, pred_boxes, pred_ious, window, (float)window_penalty, (float)(1.0 - window_penalty),
         (float)img_w, (float)img_h, unlabeled_box_extract, unlabeled_resize_factors, aug_box_extract,

@@ -11,6 +11,10 @@
 #include "common.h"
 #include "../../include/spot_hip.h"
 
+// The reference evaluates these expressions as separate rounded multiplies and adds.  HIP's
+// __fmul_rn/__fadd_rn are plain operators and hipcc fuses them by default, so this file is
+// compiled with -ffp-contract=off (see the Makefile); explicit fmaf() calls stay fused.
+
 namespace {
 
 constexpr int R = 8;  // output rows per work item
