@@ -80,6 +80,21 @@ int spot_compact_indices(const unsigned char* aug_success, int n_in, int* gather
 int spot_gather_rows(const void* src, void* dst, const int* gather_idx, int n_rows, long row_bytes,
                      hipStream_t stream);
 
+/* TransT_Tracker._convert_score + window penalty + arg-max, pysot_toolkit/trackers/transt_tracker.py:21-32,164-171.
+ * window [L] float64 (numpy hanning outer product), pscore = float64(score32 * float32(1-wp)) + window*wp.
+ * best6 [B,6] float64 = (pscore, token index, cx, cy, w, h of that token, still normalised);
+ * pscore_map [B,L] float64 or NULL. */
+int spot_tracker_decode(const float* pred_logits, const float* pred_boxes, const double* window,
+                        double window_penalty, double* best6, double* pscore_map, int B, int L,
+                        hipStream_t stream);
+
+/* TrackingMatcher.forward, ltr/models/loss/transt_matcher.py:24-109, as dense masks: pos_mask[b,t] = 1 for
+ * tokens whose cell lies in the ground-truth box gt_cxcywh[b] (normalised cx,cy,w,h; float64 ceil arithmetic
+ * as the reference's Python floats), neg_mask[b,t] = 1 for the ring of width gap around it (NULL to skip:
+ * the reference builds negatives for the supervised tag only).  Masks are [B, feat_sz*feat_sz] bytes. */
+int spot_match_masks(const float* gt_cxcywh, int B, int feat_sz, int gap, unsigned char* pos_mask,
+                     unsigned char* neg_mask, hipStream_t stream);
+
 /* ---- teacher EMA --------------------------------------------------------- */
 
 /* _update_teacher_model, ltr/actor/transt_sparse_actor.py:11-33, on flat storage:

@@ -1,0 +1,55 @@
+"""Flat parameter storage.
+
+All float32 parameters and buffers of a module are re-homed into one contiguous
+HBM allocation (and the int64 BatchNorm counters into another), in state-dict
+order; the module's tensors become views.  This is what makes the teacher EMA
+(ltr/actor/transt_sparse_actor.py:11-33) a single streaming kernel instead of
+several hundred tiny launches plus a load_state_dict, and what lets gradients
+be all-reduced in a few large RCCL buckets instead of per-tensor messages.
+"""
+import torch
+
+
+class ParamArena:
+    def __init__(self, module, with_grads=False):
+        self.module = module
+        entries = list(module.state_dict(keep_vars=True).items())
+        self.f32 = [(k, t) for k, t in entries if t.dtype == torch.float32]
+        self.i64 = [(k, t) for k, t in entries if t.dtype == torch.int64]
+        other = [k for k, t in entries if t.dtype not in (torch.float32, torch.int64)]
+        if other:
+            raise RuntimeError("ParamArena: unsupported dtypes for %s" % other)
+        dev = self.f32[0][1].device
+        # 64-float (256-byte) aligned slots so every view is 16-byte aligned for the kernels
+        offs, off = [], 0
+        for _, t in self.f32:
+            offs.append(off)
+            off += (t.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.offsets = offs
+        for (k, t), o in zip(self.f32, offs):
+            view = self.flat[o:o + t.numel()].view(t.shape)
+            view.copy_(t.data)
+            t.data = view
+        self.flat_i64 = torch.zeros(max(len(self.i64), 1), dtype=torch.int64, device=dev)
+        for j, (k, t) in enumerate(self.i64):
+            self.flat_i64[j] = t.data
+            t.data = self.flat_i64[j]
+        self.grad_flat = None
+        if with_grads:
+            self.attach_grads()
+
+    def attach_grads(self):
+        """Give every trainable parameter a .grad that is a view into one flat buffer."""
+        self.grad_flat = torch.zeros_like(self.flat)
+        for (k, t), o in zip(self.f32, self.offsets):
+            if isinstance(t, torch.nn.Parameter) and t.requires_grad:
+                t.grad = self.grad_flat[o:o + t.numel()].view(t.shape)
+        return self.grad_flat
+
+    def zero_grad(self):
+        if self.grad_flat is not None:
+            self.grad_flat.zero_()
+
+    def signature(self):
+        return [(k, tuple(t.shape)) for k, t in self.f32], [k for k, _ in self.i64]

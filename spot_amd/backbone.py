@@ -1,0 +1,170 @@
+"""Feature extraction: ResNet-50 truncated at layer3 + sine position encoding.
+
+Mirror of ltr/models/backbone/resnet.py:56-92,95-205 and
+ltr/models/backbone/transt_backbone.py:55-106 with identical state-dict keys
+(`backbone.0.body.conv1.weight`, `...layer3.5.bn3.running_var`, ...).
+
+The dense 3x3/1x1 convolutions and BatchNorm of the ResNet run through
+PyTorch-ROCm (MIOpen) — the one part of the path that is not a hand-written
+kernel yet.  Everything downstream (projection, fusion, heads, decode, filter)
+is libspot_hip.so.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from .tensordict import NestedTensor
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=dilation, bias=False,
+                               dilation=dilation)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        residual = x if self.downsample is None else self.downsample(x)
+        return self.relu(out + residual)
+
+
+class ResNet50Layer3(nn.Module):
+    """conv1 .. layer3: layer2 stride 2, layer3 stride 1 with dilation 2 in its first
+    block, total stride 8, 1024 output channels (resnet.py:103-112,152-167)."""
+
+    def __init__(self, inplanes=64):
+        super().__init__()
+        self.inplanes = inplanes
+        self.conv1 = nn.Conv2d(3, inplanes, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(inplanes)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(inplanes, 3)
+        self.layer2 = self._make_layer(inplanes * 2, 4, stride=2)
+        self.layer3 = self._make_layer(inplanes * 4, 6, stride=1, dilation=2)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, planes, blocks, stride=1, dilation=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample, dilation=dilation)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        return self.layer3(self.layer2(self.layer1(x)))
+
+
+class PositionEmbeddingSine(nn.Module):
+    """ltr/models/neck/position_encoding.py:11-45 (normalize=True, scale 2*pi, T=10000).
+
+    For the all-False masks of full-size crops the encoding is a constant of
+    (H, W): it is computed once on the host and cached per device as token rows
+    [H*W, 2*num_pos_feats].  Masked inputs take the general on-device path.
+    """
+
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=True, scale=None):
+        super().__init__()
+        self.num_pos_feats = num_pos_feats
+        self.temperature = temperature
+        self.normalize = normalize
+        self.scale = 2 * math.pi if scale is None else scale
+        self._cache = {}
+
+    def rows(self, H, W, device):
+        """Encoding of an unmasked H x W map as [H*W, C] rows (float32 arithmetic as the reference)."""
+        key = (H, W, str(device))
+        if key not in self._cache:
+            mask = torch.zeros(1, H, W, dtype=torch.bool)
+            pos = self._encode(mask)                       # [1, C, H, W] on CPU
+            self._cache[key] = pos[0].flatten(1).t().contiguous().to(device)
+        return self._cache[key]
+
+    def _encode(self, mask):
+        not_mask = (~mask).to(torch.float32)
+        y_embed = not_mask.cumsum(1)
+        x_embed = not_mask.cumsum(2)
+        if self.normalize:
+            eps = 1e-6
+            y_embed = y_embed / (y_embed[:, -1:, :] + eps) * self.scale
+            x_embed = x_embed / (x_embed[:, :, -1:] + eps) * self.scale
+        dim_t = torch.arange(self.num_pos_feats, dtype=torch.float32, device=mask.device)
+        dim_t = self.temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / self.num_pos_feats)
+        pos_x = x_embed[:, :, :, None] / dim_t
+        pos_y = y_embed[:, :, :, None] / dim_t
+        pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
+        pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
+        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+    def forward(self, tensor_list: NestedTensor):
+        assert tensor_list.mask is not None
+        return self._encode(tensor_list.mask)
+
+
+class BackboneBase(nn.Module):
+    def __init__(self, backbone, num_channels):
+        super().__init__()
+        self.body = backbone
+        self.num_channels = num_channels
+
+    def forward(self, tensor_list: NestedTensor):
+        x = self.body(tensor_list.tensors)
+        m = tensor_list.mask
+        assert m is not None
+        mask = torch.nn.functional.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]
+        return {"layer3": NestedTensor(x, mask)}
+
+
+class Backbone(BackboneBase):
+    def __init__(self, output_layers=("layer3",), pretrained=False, frozen_layers=()):
+        if pretrained:
+            raise RuntimeError("spot_amd: pretrained ImageNet weights are a network download in the reference "
+                               "(resnet.py:256-257); load a checkpoint with load_state_dict instead")
+        super().__init__(ResNet50Layer3(), 1024)
+
+
+class Joiner(nn.Sequential):
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+
+    def forward(self, tensor_list: NestedTensor):
+        xs = self[0](tensor_list)
+        out, pos = [], []
+        for _, x in xs.items():
+            out.append(x)
+            pos.append(self[1](x).to(x.tensors.dtype))
+        return out, pos
+
+
+def build_backbone(settings, backbone_pretrained=False, frozen_backbone_layers=()):
+    position_embedding = PositionEmbeddingSine(settings.hidden_dim // 2, normalize=True)
+    backbone = Backbone(pretrained=backbone_pretrained, frozen_layers=frozen_backbone_layers)
+    model = Joiner(backbone, position_embedding)
+    model.num_channels = backbone.num_channels
+    return model

@@ -264,3 +264,105 @@ extern "C" int spot_gather_rows(const void* src, void* dst, const int* gather_id
     SPOT_CHECK_LAUNCH("gather_rows");
     return SPOT_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Matcher (ltr/models/loss/transt_matcher.py:24-109): tokens whose cell index lies in
+// the ground-truth box are positives; a ring of width `gap` around them are the
+// IoU-head negatives.  The reference does this arithmetic in Python floats
+// (float64) on .item() values, hence the doubles.  One thread per token.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void match_masks_kernel(const float* __restrict__ gt, int n, int gap,
+                                                          unsigned char* __restrict__ pos,
+                                                          unsigned char* __restrict__ neg, int B) {
+    const int L = n * n;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * L) return;
+    const int b = (int)(i / L), t = (int)(i % L), y = t / n, x = t % n;
+    const double cx = gt[4 * b], cy = gt[4 * b + 1], w = gt[4 * b + 2], h = gt[4 * b + 3];
+    int X0 = max((int)ceil((cx - w / 2) * n), 0), Y0 = max((int)ceil((cy - h / 2) * n), 0);
+    int X1 = min((int)ceil((cx + w / 2) * n), n), Y1 = min((int)ceil((cy + h / 2) * n), n);
+    if (X0 == X1) X1 += 1;
+    if (Y0 == Y1) Y1 += 1;
+    const bool p = y >= Y0 && y < Y1 && x >= X0 && x < X1;
+    pos[i] = p ? 1 : 0;
+    if (neg) {
+        const int Yo0 = max(0, Y0 - gap), Yo1 = min(n, Y1 + gap), Xo0 = max(0, X0 - gap), Xo1 = min(n, X1 + gap);
+        const bool in_outer = y >= Yo0 && y < Yo1 && x >= Xo0 && x < Xo1;
+        // union of the four rectangles of :92-95 == outer rectangle minus [Y0,Y1) x [X0,X1)
+        const bool in_inner = y >= Y0 && y < Y1 && x >= X0 && x < X1;
+        neg[i] = (in_outer && !in_inner) ? 1 : 0;
+    }
+}
+}  // namespace
+
+extern "C" int spot_match_masks(const float* gt_cxcywh, int B, int feat_sz, int gap, unsigned char* pos_mask,
+                                unsigned char* neg_mask, hipStream_t stream) {
+    SPOT_CHECK_ARG(B >= 0 && feat_sz > 0 && gap >= 0, "match_masks: bad B=%d feat_sz=%d gap=%d", B, feat_sz, gap);
+    if (B == 0) return SPOT_OK;
+    SPOT_CHECK_ARG(gt_cxcywh && pos_mask, "match_masks: null pointer");
+    const long total = (long)B * feat_sz * feat_sz;
+    match_masks_kernel<<<(int)((total + 255) / 256), 256, 0, stream>>>(gt_cxcywh, feat_sz, gap, pos_mask, neg_mask, B);
+    SPOT_CHECK_LAUNCH("match_masks");
+    return SPOT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Online tracker post-processing (pysot_toolkit/trackers/transt_tracker.py:21-32,164-171):
+// softmax[:, 0] in fp32, pscore = score*(1-wp) + window*wp in float64 (the reference mixes a
+// float32 score array with a float64 numpy window), arg-max, and the raw box of that token.
+// One workgroup per frame; outputs stay on the device until the host needs the 4+1 numbers.
+// ---------------------------------------------------------------------------
+namespace {
+struct BestD {
+    double v;
+    int i;
+};
+__device__ __forceinline__ BestD better_d(BestD a, BestD b) {
+    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+__global__ __launch_bounds__(256) void tracker_decode_kernel(const float* __restrict__ logits,
+                                                             const float* __restrict__ boxes,
+                                                             const double* __restrict__ window, float omwp, double wp,
+                                                             double* __restrict__ out /* [B,6]: pscore,idx,cx,cy,w,h */,
+                                                             double* __restrict__ pscore_map, int L) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ BestD s_best[4];
+    const float2* lg = reinterpret_cast<const float2*>(logits) + (size_t)b * L;
+    BestD best{-1e300, 0x7fffffff};
+    for (int t = tid; t < L; t += 256) {
+        const float2 l = lg[t];
+        const float m = fmaxf(l.x, l.y);
+        const float e0 = expf(l.x - m), e1 = expf(l.y - m);
+        const float s = e0 / (e0 + e1);
+        const double v = (double)(s * omwp) + window[t] * wp;
+        if (pscore_map) pscore_map[(size_t)b * L + t] = v;
+        best = better_d(best, BestD{v, t});
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        BestD other{__shfl_xor(best.v, o), __shfl_xor(best.i, o)};
+        best = better_d(best, other);
+    }
+    if ((tid & 63) == 0) s_best[tid >> 6] = best;
+    __syncthreads();
+    if (tid != 0) return;
+    best = better_d(better_d(s_best[0], s_best[1]), better_d(s_best[2], s_best[3]));
+    const float4 bb = reinterpret_cast<const float4*>(boxes)[(size_t)b * L + best.i];
+    double* o = out + 6 * (size_t)b;
+    o[0] = best.v; o[1] = (double)best.i; o[2] = bb.x; o[3] = bb.y; o[4] = bb.z; o[5] = bb.w;
+}
+}  // namespace
+
+extern "C" int spot_tracker_decode(const float* pred_logits, const float* pred_boxes, const double* window,
+                                   double window_penalty, double* best6, double* pscore_map, int B, int L,
+                                   hipStream_t stream) {
+    SPOT_CHECK_ARG(B >= 0 && L > 0, "tracker_decode: bad B=%d L=%d", B, L);
+    if (B == 0) return SPOT_OK;
+    SPOT_CHECK_ARG(pred_logits && pred_boxes && window && best6, "tracker_decode: null pointer");
+    tracker_decode_kernel<<<B, 256, 0, stream>>>(pred_logits, pred_boxes, window, (float)(1.0 - window_penalty),
+                                                 window_penalty, best6, pscore_map, L);
+    SPOT_CHECK_LAUNCH("tracker_decode");
+    return SPOT_OK;
+}

@@ -38,6 +38,8 @@ SIGNATURES = {
                                vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "spot_compact_indices": [vp, i32, vp, i32, vp, vp],
     "spot_gather_rows": [vp, vp, vp, i32, i64, vp],
+    "spot_tracker_decode": [vp, vp, vp, f64, vp, vp, i32, i32, vp],
+    "spot_match_masks": [vp, i32, i32, i32, vp, vp, vp],
     "spot_ema_lerp_f32": [vp, vp, i64, f64, vp],
     "spot_ema_lerp_i64": [vp, vp, i32, f64, vp],
     "spot_box_iou_pair_f32": [vp, vp, i32, vp, vp, vp, i32, vp],

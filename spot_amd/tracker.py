@@ -1,0 +1,176 @@
+"""Online tracker API: host mirror of pysot_toolkit/trackers/transt_tracker.py:12-193 and
+pysot_toolkit/trackers/net_wrappers.py:4-56.
+
+``TransT_Tracker(name, net, window_penalty, exemplar_size, instance_size)`` with
+``initialize(image, {'init_bbox': [x,y,w,h]}) -> {'time'}`` and
+``track(image) -> {'target_bbox': [x,y,w,h], 'best_score': pscore}``.
+
+Per frame: the crop is cut on the host (numpy, as the reference), uploaded as
+uint8 (a quarter of the reference's float32 upload), normalised by the
+preprocess kernel, pushed through backbone + fusion + heads, and the 1024-token
+score map is reduced on the device; one small buffer (the chosen box and the
+pscore map the reference also returns) comes back per frame.  cv2 is not
+available here: when the crop must be rescaled, a bilinear resize on the GPU
+stands in for cv2.resize (outside the parity contract, which is stated at the
+network boundary).
+"""
+import math
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import lib, ops
+
+
+class NetWithBackbone:
+    """Lazy network holder (net_wrappers.py:4-56): .initialize() moves to GPU and sets eval()."""
+
+    def __init__(self, net_path=None, use_gpu=True, initialize=False, net=None, **kwargs):
+        self.net_path = net_path
+        self.use_gpu = use_gpu
+        self.net = net
+        self.net_kwargs = kwargs
+        if initialize:
+            self.initialize()
+
+    def __getattr__(self, name):
+        if name in ("net", "net_path", "use_gpu", "net_kwargs"):
+            raise AttributeError(name)
+        return getattr(self.net, name)
+
+    def load_network(self):
+        if self.net is None:
+            from .transt import transt_resnet50
+            from .synthetic import Settings
+            self.net = transt_resnet50(Settings(device="cuda" if self.use_gpu else "cpu"))
+            if self.net_path is not None:
+                ckpt = torch.load(self.net_path, map_location="cpu", weights_only=True)
+                self.net.load_state_dict(ckpt["net"] if "net" in ckpt else ckpt)
+        if self.use_gpu:
+            self.net.cuda()
+        self.net.eval()
+
+    def initialize(self):
+        self.load_network()
+
+    def template(self, z):
+        with torch.no_grad():
+            self.net.template(z)
+
+    def track(self, x):
+        with torch.no_grad():
+            return self.net.track(x)
+
+
+class TransT_Tracker(object):
+    def __init__(self, name, net, window_penalty=0.49, exemplar_size=128, instance_size=256):
+        self.name = name
+        self.net = net
+        self.window_penalty = window_penalty
+        self.exemplar_size = exemplar_size
+        self.instance_size = instance_size
+        self.mean = [0.485, 0.456, 0.406]
+        self.std = [0.229, 0.224, 0.225]
+
+    def _bbox_clip(self, cx, cy, width, height, boundary):
+        cx = max(0, min(cx, boundary[1]))
+        cy = max(0, min(cy, boundary[0]))
+        width = max(10, min(width, boundary[1]))
+        height = max(10, min(height, boundary[0]))
+        return cx, cy, width, height
+
+    def get_subwindow(self, im, pos, model_sz, original_sz, avg_chans):
+        """Square crop of side original_sz around pos, padded with the channel average
+        (transt_tracker.py:41-101); returned as a uint8 [1,3,model_sz,model_sz] device tensor."""
+        if isinstance(pos, float):
+            pos = [pos, pos]
+        sz = original_sz
+        im_sz = im.shape
+        c = (original_sz + 1) / 2
+        context_xmin = np.floor(pos[0] - c + 0.5)
+        context_xmax = context_xmin + sz - 1
+        context_ymin = np.floor(pos[1] - c + 0.5)
+        context_ymax = context_ymin + sz - 1
+        left_pad = int(max(0., -context_xmin))
+        top_pad = int(max(0., -context_ymin))
+        right_pad = int(max(0., context_xmax - im_sz[1] + 1))
+        bottom_pad = int(max(0., context_ymax - im_sz[0] + 1))
+        context_xmin, context_xmax = context_xmin + left_pad, context_xmax + left_pad
+        context_ymin, context_ymax = context_ymin + top_pad, context_ymax + top_pad
+        r, c_, k = im.shape
+        if any([top_pad, bottom_pad, left_pad, right_pad]):
+            te_im = np.zeros((r + top_pad + bottom_pad, c_ + left_pad + right_pad, k), np.uint8)
+            te_im[top_pad:top_pad + r, left_pad:left_pad + c_, :] = im
+            if top_pad:
+                te_im[0:top_pad, left_pad:left_pad + c_, :] = avg_chans
+            if bottom_pad:
+                te_im[r + top_pad:, left_pad:left_pad + c_, :] = avg_chans
+            if left_pad:
+                te_im[:, 0:left_pad, :] = avg_chans
+            if right_pad:
+                te_im[:, c_ + left_pad:, :] = avg_chans
+            patch = te_im[int(context_ymin):int(context_ymax + 1), int(context_xmin):int(context_xmax + 1), :]
+        else:
+            patch = im[int(context_ymin):int(context_ymax + 1), int(context_xmin):int(context_xmax + 1), :]
+        t = torch.from_numpy(np.ascontiguousarray(patch.transpose(2, 0, 1)[np.newaxis])).cuda(non_blocking=True)
+        if model_sz != original_sz:
+            t = F.interpolate(t.float(), size=(model_sz, model_sz), mode="bilinear", align_corners=False)
+            t = t.round().clamp(0, 255).to(torch.uint8)
+        return t.contiguous()
+
+    def _normalize(self, crop_u8):
+        return ops.preprocess_u8(crop_u8, None, self.mean, self.std)
+
+    def initialize_features(self):
+        if not getattr(self, "features_initialized", False):
+            self.net.initialize()
+        self.features_initialized = True
+
+    def initialize(self, image, info: dict) -> dict:
+        tic = time.time()
+        hanning = np.hanning(32)
+        self.window = np.outer(hanning, hanning).flatten()
+        self._window_dev = torch.from_numpy(self.window).cuda()
+        self.initialize_features()
+        bbox = info["init_bbox"]
+        self.center_pos = np.array([bbox[0] + bbox[2] / 2, bbox[1] + bbox[3] / 2])
+        self.size = np.array([bbox[2], bbox[3]])
+        w_z = self.size[0] + (2 - 1) * ((self.size[0] + self.size[1]) * 0.5)
+        h_z = self.size[1] + (2 - 1) * ((self.size[0] + self.size[1]) * 0.5)
+        s_z = math.ceil(math.sqrt(w_z * h_z))
+        self.channel_average = np.mean(image, axis=(0, 1))
+        z_crop = self.get_subwindow(image, self.center_pos, self.exemplar_size, s_z, self.channel_average)
+        self.net.template(self._normalize(z_crop))
+        return {"time": time.time() - tic}
+
+    def decode(self, outputs):
+        """Device-side score conversion, window penalty and arg-max for one frame.
+
+        Returns one float64 buffer [6 + L]: (pscore, token, cx, cy, w, h) then the pscore map."""
+        lg, bx = outputs["pred_logits"].contiguous(), outputs["pred_boxes"].contiguous()
+        B, L, _ = lg.shape
+        assert B == 1, "the online tracker handles one frame at a time"
+        buf = torch.empty((6 + L,), dtype=torch.float64, device=lg.device)
+        lib.call("spot_tracker_decode", ops._p(lg), ops._p(bx), ops._p(self._window_dev), float(self.window_penalty),
+                 ops._p(buf), ops._p(buf[6:]), B, L, ops._st())
+        return buf
+
+    def track(self, image, info: dict = None) -> dict:
+        w_x = self.size[0] + (4 - 1) * ((self.size[0] + self.size[1]) * 0.5)
+        h_x = self.size[1] + (4 - 1) * ((self.size[0] + self.size[1]) * 0.5)
+        s_x = math.ceil(math.sqrt(w_x * h_x))
+        x_crop = self.get_subwindow(image, self.center_pos, self.instance_size, round(s_x), self.channel_average)
+        outputs = self.net.track(self._normalize(x_crop))
+        res = self.decode(outputs).cpu().numpy()               # the frame's one device->host read
+        bx, by, bw, bh = res[2:6]
+        pscore = res[6:]
+        bbox = np.array([bx, by, bw, bh], dtype=np.float32) * s_x
+        cx = bbox[0] + self.center_pos[0] - s_x / 2
+        cy = bbox[1] + self.center_pos[1] - s_x / 2
+        cx, cy, width, height = self._bbox_clip(cx, cy, bbox[2], bbox[3], image.shape[:2])
+        self.center_pos = np.array([cx, cy])
+        self.size = np.array([width, height])
+        out_bbox = [cx - width / 2, cy - height / 2, width, height]
+        return {"target_bbox": out_bbox, "best_score": pscore}

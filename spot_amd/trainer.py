@@ -1,0 +1,120 @@
+"""Sparsely-supervised training loop (hot loop only) on the HIP kernels.
+
+Host mirror of ltr/trainers/ltr_sparse_trainer.py:90-140,242-377: per iteration
+  teacher EMA every `teacher_update_frequency` iterations -> teacher pseudo-labels
+  -> middleware filter -> keep/refill compaction -> student step.
+Checkpointing, tensorboard and the DataLoader assembly of the reference are out
+of scope; `loader_sup` / `loader_unsup` are any iterables yielding the same
+TensorDicts (see synthetic.py).
+
+What changed for the hardware:
+  * everything between the two network passes stays on the GPU: decode, filter
+    and compaction are kernels, the refill is a row gather by index
+    (ltr_sparse_trainer.py:334-357 builds Python lists of per-sample tensors);
+  * one host read per iteration decides "skip" (no valid pseudo label, or a
+    non-finite loss), and the decision is made rank-consistent with a MIN
+    all-reduce so data-parallel ranks never diverge;
+  * gradients live in one flat buffer and are all-reduced in buckets that overlap
+    backward (dist.py); the optimizer is created over the same parameters.
+"""
+import time
+
+import torch
+
+from . import ops
+from .arena import ParamArena
+from .dist import GradBucketReducer, all_ranks_ok, world_size
+from .tensordict import TensorDict
+
+
+class LTRSparseTrainer:
+    def __init__(self, actor, loader_assemble, optimizer, settings, middleware, lr_scheduler=None):
+        self.actor = actor
+        self.loader_assemble = loader_assemble
+        self.optimizer = optimizer
+        self.settings = settings
+        self.middleware = middleware
+        self.lr_scheduler = lr_scheduler
+        self.device = torch.device(getattr(settings, "device", "cuda"))
+        self.move_data_to_gpu = getattr(settings, "move_data_to_gpu", True)
+        self.epoch = 0
+        self.stats = {}
+        stu = actor.student_net.module if hasattr(actor.student_net, "module") else actor.student_net
+        self.arena = getattr(stu, "_spot_arena", None) or ParamArena(stu)
+        stu._spot_arena = self.arena
+        self.reducer = GradBucketReducer(self.arena)
+        self.num_frames = 0
+        self.skipped = 0
+
+    # -- one epoch over the two loaders ----------------------------------------
+    def cycle_dataset_sparse_supervised(self, loader_sup, loader_unsup, training=True):
+        self.num_frames, self.start_time = 0, time.time()
+        last = None
+        for i, (data_sup, (data_unsup, middle_info)) in enumerate(zip(loader_sup, loader_unsup)):
+            last = self.train_iteration(i, data_sup, data_unsup, middle_info, training)
+        return last
+
+    def train_iteration(self, i, data_sup, data_unsup, middle_info, training=True):
+        if (i + 1) % self.settings.teacher_update_frequency == 0:
+            self._teacher_model_update(keep_rate=self.settings.keep_rate)
+        if self.move_data_to_gpu:
+            data_unsup = data_unsup.to(self.device, non_blocking=True)
+            data_sup = data_sup.to(self.device, non_blocking=True)
+        pseudo_label = self._pseudo_label_generation(data_unsup)
+        aug_label = self._middleware_ops(middle_info, pseudo_label)
+        loss, stats, n_keep = self._sparse_training(data_sup, data_unsup, aug_label, training)
+        # single host read: kept count and loss finiteness
+        flags = torch.stack([n_keep.float().reshape(()), torch.isfinite(loss.detach()).float().reshape(())]).tolist()
+        ok = all_ranks_ok(flags[0] > 0 and flags[1] > 0, self.device)
+        if not ok:
+            self.skipped += 1
+            return None
+        if training:
+            self.arena.zero_grad()
+            self.reducer.arm()
+            loss.backward()
+            self.reducer.finish()
+            self.optimizer.step()
+        self.num_frames += self.settings.batch_size
+        return stats
+
+    # -- pieces (names follow the reference) --------------------------------------
+    def _teacher_model_update(self, keep_rate=0.998):
+        self.actor.train(False)
+        with torch.no_grad():
+            self.actor(mode="update", keep_rate=keep_rate)
+
+    def _pseudo_label_generation(self, data):
+        self.actor.train(False)
+        with torch.no_grad():
+            data_load = TensorDict()
+            for prefix in ("key", "unlabeled"):
+                for suffix in ("images", "anno", "avg"):
+                    data_load["{}_{}".format(prefix, suffix)] = data["{}_{}".format(prefix, suffix)]
+            return self.actor(mode="inference", teacher_data=data_load)
+
+    def _middleware_ops(self, middle_info, pseudo_label):
+        return self.middleware.record_relay_results(middle_info, pseudo_label)
+
+    def compact(self, data_unsup, aug_label):
+        """Keep successful clips in order and refill cyclically to batch_size_unsup (:334-357)."""
+        n_out = self.settings.batch_size_unsup
+        keep = aug_label.get("aug_success_u8")
+        if keep is None:
+            keep = aug_label["aug_success"].to(torch.uint8)
+        idx, n_keep = ops.compact_indices(keep.contiguous(), n_out)
+        src = dict(data_unsup)
+        src["aug_anno"] = aug_label["aug_anno"]
+        out = TensorDict()
+        for prefix in ("relay", "aug"):
+            for suffix in ("images", "anno", "avg"):
+                key = "{}_{}".format(prefix, suffix)
+                out[key] = ops.gather_rows(src[key].contiguous(), idx)
+        return out, n_keep, idx
+
+    def _sparse_training(self, data_sup, data_unsup, aug_label, training=True):
+        self.actor.train(training)
+        with torch.set_grad_enabled(training):
+            data_load, n_keep, _ = self.compact(data_unsup, aug_label)
+            loss, stats = self.actor(mode="spsup", burnin_data=data_sup, sp_data=data_load)
+        return loss, stats, n_keep

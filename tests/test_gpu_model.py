@@ -1,0 +1,187 @@
+"""End-to-end parity of the host modules + HIP kernels against goldens produced by the reference
+(teacher pseudo-labelling, student step, EMA, tracker post-processing).  Needs a real MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import spot_oracle as O
+from spot_amd.detinit import det_fill_, det_input
+from spot_amd.synthetic import Settings, sup_batch, unsup_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def G(a):
+    return T(a).to(DEV)
+
+
+def build(seed, dropout=0.1):
+    from spot_amd.transt import transt_resnet50
+    net = transt_resnet50(Settings(device="cpu", dropout=dropout))
+    det_fill_(net, seed)
+    return net.to(DEV)
+
+
+def test_teacher_pseudo_label_pipeline_golden(golden):
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.middleware import SparseMiddleware
+    from spot_amd.tensordict import TensorDict
+    g = golden("g5_teacher")
+    B, seed = int(g["B"]), int(g["seed"])
+    S = Settings()
+    net = build(seed).eval()
+    with torch.no_grad():
+        net.iou_embed.layers[2].bias += float(g["iou_bias_shift"])
+    actor = TranstSparseActor(S, net, net, None)
+    data = TensorDict({
+        "key_images": G(det_input("key_images", (B, 3, 128, 128), seed, 0, 256, np.uint8)),
+        "unlabeled_images": G(det_input("unlabeled_images", (B, 3, 256, 256), seed, 0, 256, np.uint8)),
+        "key_avg": G(det_input("key_avg", (B, 3), seed, 0, 255)),
+        "unlabeled_avg": G(det_input("unlabeled_avg", (B, 3), seed, 0, 255)),
+        "key_anno": G(det_input("key_anno", (B, 4), seed, 20, 80)),
+        "unlabeled_anno": G(det_input("unlabeled_anno", (B, 4), seed, 40, 120))})
+    with torch.no_grad():
+        raw = net(teacher_data=TensorDict(data))
+    # score maps / boxes: 1e-3 relative (fp32), as the parity contract states
+    np.testing.assert_allclose(raw["pred_logits"].cpu().numpy(), g["pred_logits"], rtol=1e-3, atol=5e-4)
+    np.testing.assert_allclose(raw["pred_boxes"].cpu().numpy(), g["pred_boxes"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(raw["pred_ious"].cpu().numpy(), g["pred_ious"], rtol=1e-3, atol=1e-4)
+    pseudo = actor(mode="inference", teacher_data=TensorDict(data))
+    np.testing.assert_allclose(pseudo["best_bbox"].cpu().numpy(), g["best_bbox"], atol=0.5)       # 0.5 px
+    np.testing.assert_allclose(pseudo["best_score"].cpu().numpy(), g["best_score"], rtol=1e-3)
+    np.testing.assert_allclose(pseudo["best_conf"].cpu().numpy(), g["best_conf"], rtol=1e-3)
+    xy, wh = det_input("unl_xy", (B, 1, 2), seed, 0, 400), det_input("unl_wh", (B, 1, 2), seed, 20, 200)
+    ue = np.concatenate([xy, wh], -1).astype(np.float32)
+    xy, wh = det_input("aug_xy", (B, 1, 2), seed, 0, 400), det_input("aug_wh", (B, 1, 2), seed, 20, 200)
+    ae = np.concatenate([xy, wh], -1).astype(np.float32)
+    mid = {"unlabeled_box_extract": T(ue), "unlabeled_resize_factors": T(det_input("unl_rf", (B,), seed, 0.5, 2.0)),
+           "aug_box_extract": T(ae), "aug_resize_factors": T(det_input("aug_rf", (B,), seed, 0.5, 2.0))}
+    res = SparseMiddleware(S).record_relay_results(mid, pseudo)
+    assert np.array_equal(res["aug_success"].cpu().numpy(), g["aug_success"])                     # identical keep mask
+    np.testing.assert_allclose(res["aug_anno"].cpu().numpy(), g["aug_anno"], atol=0.5)
+
+
+def test_student_step_golden(golden):
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.criterion import transt_loss
+    from spot_amd.tensordict import TensorDict
+    from tests.test_oracle_model import student_batches
+    g = golden("g15_student")
+    seed, bs, bu = int(g["seed"]), int(g["bs"]), int(g["bu"])
+    S = Settings(dropout=0.0)
+    net = build(seed, dropout=0.0).train()
+    actor = TranstSparseActor(S, net, net, transt_loss(S))
+    sup, sp = student_batches(seed, bs, bu)
+    sup = TensorDict({k: v.to(DEV) for k, v in sup.items()})
+    sp = TensorDict({k: v.to(DEV) for k, v in sp.items()})
+    loss, stats = actor(mode="spsup", burnin_data=sup, sp_data=sp)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-3)
+    stats = actor.stats_to_float(stats)
+    ref_stats = dict(zip([str(k) for k in g["stat_keys"]], g["stat_vals"]))
+    for k, v in ref_stats.items():
+        np.testing.assert_allclose(stats[k], v, rtol=2e-3, atol=1e-5, err_msg=k)
+    loss.backward()
+    gn = dict(zip([str(k) for k in g["gn_keys"]], g["gn_vals"]))
+    params = dict(net.named_parameters())
+    worst = max(abs(float(p.grad.norm()) - gn[k]) / gn[k] for k, p in params.items() if gn.get(k, 0) > 1e-6)
+    assert worst < 2e-2, worst
+    for k in [n[len("gslice."):] for n in g.files if n.startswith("gslice.")]:
+        ref = g["gslice." + k]
+        np.testing.assert_allclose(params[k].grad.reshape(-1)[:64].cpu().numpy(), ref, rtol=2e-2,
+                                   atol=2e-3 * max(1e-6, float(np.abs(ref).max())), err_msg=k)
+
+
+def test_ema_over_arena_matches_oracle():
+    from spot_amd.actor import TranstSparseActor
+    stu, tea = build(5), build(6)
+    tea.backbone[0].body.bn1.num_batches_tracked.fill_(100)
+    stu.backbone[0].body.bn1.num_batches_tracked.fill_(7)
+    before_t = {k: v.detach().cpu().clone() for k, v in tea.state_dict().items()}
+    before_s = {k: v.detach().cpu().clone() for k, v in stu.state_dict().items()}
+    actor = TranstSparseActor(Settings(), stu, tea, None)
+    actor(mode="update", keep_rate=0.998)
+    ref = O.ema_update(before_t, before_s, 0.998)
+    for k, v in tea.state_dict().items():
+        assert torch.equal(v.cpu(), ref[k]), k
+    for k, v in stu.state_dict().items():
+        assert torch.equal(v.cpu(), before_s[k]), k
+    actor(mode="update", keep_rate=0)
+    for k, v in tea.state_dict().items():
+        assert torch.equal(v.cpu().float(), before_s[k].float()), k
+
+
+def test_trainer_iteration_end_to_end():
+    """Teacher -> decode -> filter -> compaction -> student step runs on device and updates the student;
+    compaction matches the oracle rule on the kernel's own keep mask."""
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.criterion import transt_loss
+    from spot_amd.middleware import SparseMiddleware
+    from spot_amd.trainer import LTRSparseTrainer
+    S = Settings(dropout=0.0, batch_size_sup=2, batch_size_unsup=6, teacher_update_frequency=1)
+    S.curriculum_settings["confidence_threshold"] = 0.5
+    stu, tea = build(7, 0.0), build(7, 0.0)
+    actor = TranstSparseActor(S, stu, tea, transt_loss(S))
+    opt = torch.optim.AdamW([p for p in stu.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
+    trainer = LTRSparseTrainer(actor, None, opt, S, SparseMiddleware(S))
+    data_unsup, mid = unsup_batch(6, 3, device=DEV)
+    data_sup = sup_batch(2, 3, device=DEV)
+    pseudo = trainer._pseudo_label_generation(data_unsup)
+    aug = trainer._middleware_ops(mid, pseudo)
+    _, n_keep, idx = trainer.compact(data_unsup, aug)
+    keep = aug["aug_success"].cpu().numpy()
+    ref_idx = O.compact_indices(keep, 6)
+    if ref_idx is None:
+        assert int(n_keep.item()) == 0
+    else:
+        assert np.array_equal(idx.cpu().numpy(), ref_idx.astype(np.int32))
+    w0 = stu.class_embed.layers[2].weight.detach().clone()
+    stats = trainer.train_iteration(0, data_sup, data_unsup, mid)
+    if keep.any():
+        assert stats is not None and torch.isfinite(stats["Loss/total"])
+        assert not torch.equal(w0, stu.class_embed.layers[2].weight.detach())
+
+
+def test_tracker_post_processing_golden(golden):
+    from spot_amd.tracker import TransT_Tracker
+    g = golden("g11_tracker_post")
+
+    class Net:
+        def initialize(self):
+            pass
+
+        def template(self, z):
+            pass
+
+        def track(self, x):
+            return {"pred_logits": G(g["logits"][self.i]), "pred_boxes": G(g["boxes"][self.i])}
+
+    net = Net()
+    trk = TransT_Tracker("g", net, window_penalty=0.49, exemplar_size=128, instance_size=256)
+    img = np.zeros((int(g["image_hw"][0]), int(g["image_hw"][1]), 3), np.uint8)
+    trk.initialize(img, {"init_bbox": [float(v) for v in g["init_bbox"]]})
+    for i in range(g["logits"].shape[0]):
+        net.i = i
+        o = trk.track(img)
+        np.testing.assert_allclose(o["target_bbox"], g["target_bbox"][i], rtol=1e-6, atol=1e-3)
+        np.testing.assert_allclose(np.max(o["best_score"]), g["best"][i], rtol=1e-6)
+        np.testing.assert_allclose(trk.center_pos, g["center"][i], rtol=1e-6, atol=1e-3)
+        np.testing.assert_allclose(trk.size, g["size"][i], rtol=1e-6, atol=1e-3)
+
+
+def test_tracker_runs_on_synthetic_sequence():
+    """cfg-1 shape: 256x256 frames, template 128^2 cached once, track() per frame."""
+    from spot_amd.tracker import NetWithBackbone, TransT_Tracker
+    net = NetWithBackbone(net=build(1), use_gpu=True)
+    trk = TransT_Tracker("t", net, 0.49, 128, 256)
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 255, size=(4, 256, 256, 3), dtype=np.uint8)
+    trk.initialize(frames[0], {"init_bbox": [96.0, 96.0, 64.0, 64.0]})
+    for f in frames[1:]:
+        o = trk.track(f)
+        assert len(o["target_bbox"]) == 4 and np.all(np.isfinite(o["target_bbox"]))
+        assert o["best_score"].shape == (1024,)
