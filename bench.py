@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark of the SPOT tracker hot path on MI355X.
+
+One step = one iteration of the sparsely-supervised loop on a synthetic batch that is already
+resident in HBM: (teacher EMA every 5th step) -> teacher pseudo-labelling of 32 clips (backbone,
+fusion, heads) -> decode -> IoU-confidence filter -> keep/refill compaction -> student forward on
+8 labelled + 32 pseudo-labelled pairs -> losses -> backward -> (RCCL gradient all-reduce) -> AdamW.
+value = clips pseudo-labelled AND trained on per second, whole job (all ranks).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def build_world(args):
+    from spot_amd import dist as sdist
+    rank, world, local = sdist.init_from_env("nccl")
+    torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def build_job(args, rank):
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.arena import ParamArena
+    from spot_amd.criterion import transt_loss
+    from spot_amd.detinit import det_fill_
+    from spot_amd.middleware import SparseMiddleware
+    from spot_amd.synthetic import Settings, sup_batch, unsup_batch
+    from spot_amd.trainer import LTRSparseTrainer
+    from spot_amd.transt import transt_resnet50
+
+    S = Settings(device="cuda", dropout=0.0, batch_size_sup=args.sup, batch_size_unsup=args.clips)
+    stu = det_fill_(transt_resnet50(Settings(device="cpu", dropout=0.0)), 0).cuda()
+    tea = det_fill_(transt_resnet50(Settings(device="cpu", dropout=0.0)), 0).cuda()
+    stu._spot_arena = ParamArena(stu)
+    tea._spot_arena = ParamArena(tea)
+    actor = TranstSparseActor(S, stu, tea, transt_loss(S))
+    lr, wd, br = (S.optimizer_parameters[k] for k in ("learning_rate", "weight_decay", "backbone_ratio"))
+    groups = [{"params": [p for n, p in stu.named_parameters() if "backbone" not in n and p.requires_grad]},
+              {"params": [p for n, p in stu.named_parameters() if "backbone" in n and p.requires_grad], "lr": br * lr}]
+    opt = torch.optim.AdamW(groups, lr=lr, weight_decay=wd)
+    trainer = LTRSparseTrainer(actor, None, opt, S, SparseMiddleware(S))
+    data_unsup, mid = unsup_batch(args.clips, 1 + rank, device="cuda")
+    data_sup = sup_batch(args.sup, 1 + rank, device="cuda")
+    mid = {k: v.cuda() for k, v in mid.items()}
+    # Random weights give arbitrary IoU-head confidences; shift the teacher's final IoU bias once so that
+    # about 3 of 4 clips pass tau = 0.85 (a trained teacher's regime) instead of none or all.
+    with torch.no_grad():
+        pseudo = trainer._pseudo_label_generation(data_unsup)
+        conf = pseudo["best_conf"].clamp(1e-6, 1 - 1e-6)
+        logit = torch.log(conf / (1 - conf))
+        target = torch.log(torch.tensor(0.85 / 0.15, device="cuda"))
+        shift = target - torch.quantile(logit, 0.25)
+        tea.iou_embed.layers[2].bias += shift
+        stu.iou_embed.layers[2].bias += shift
+    return S, trainer, data_sup, data_unsup, mid
+
+
+def cpu_baseline(args):
+    """The oracle (a port of the reference's PyTorch-CPU path) on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import spot_oracle as O
+    from spot_amd.detinit import det_state_dict, det_input
+    from spot_amd.synthetic import Settings
+    from spot_amd.transt import transt_resnet50
+    threads = torch.get_num_threads()
+    S = Settings(device="cpu")
+    net = transt_resnet50(Settings(device="cpu", dropout=0.0))
+    names = {k for k, _ in net.named_parameters()}
+    sd = {k: (v.float().requires_grad_() if k in names else v) for k, v in det_state_dict(net, 0).items()}
+    n_unsup, n_sup = 4, 1
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    key = T(det_input("key_images", (n_unsup, 3, 128, 128), 1, 0, 256, np.uint8))
+    unl = T(det_input("unlabeled_images", (n_unsup, 3, 256, 256), 1, 0, 256, np.uint8))
+    tmpl = T(det_input("template_images", (n_sup + n_unsup, 3, 128, 128), 1, 0, 256, np.uint8))
+    srch = T(det_input("search_images", (n_sup + n_unsup, 3, 256, 256), 1, 0, 256, np.uint8))
+    anno = T(np.concatenate([det_input("xy", (n_sup + n_unsup, 2), 1, 40, 110),
+                             det_input("wh", (n_sup + n_unsup, 2), 1, 40, 100)], -1).astype(np.float32))
+    ext = T(np.concatenate([det_input("exy", (n_unsup, 2), 1, 0, 400), det_input("ewh", (n_unsup, 2), 1, 20, 200)], -1)
+            .astype(np.float32))
+    rf = T(det_input("rf", (n_unsup,), 1, 0.5, 2.0))
+    t0 = time.time()
+    reps = 0
+    while reps < 1 or time.time() - t0 < 10.0:
+        with torch.no_grad():
+            out = O.transt_forward(key, unl, sd)
+            dec = O.decode_teacher(out["pred_logits"], out["pred_boxes"], out["pred_ious"], 0.40, 32, 256, 256)
+            flt = O.middleware_filter(dec["best_bbox"], dec["best_conf"], ext, rf, ext, rf, 256, 0.85)
+            O.compact_indices(flt["aug_success"].numpy() | True, n_unsup)
+        o = O.transt_forward(tmpl, srch, sd, b_iou=n_sup, training=True)
+        loss, _, _ = O.sp_training_loss({"logits": o["pred_logits"][:n_sup], "boxes": o["pred_boxes"][:n_sup],
+                                         "ious": o["pred_ious"]},
+                                        {"logits": o["pred_logits"][n_sup:], "boxes": o["pred_boxes"][n_sup:]},
+                                        anno[:n_sup], anno[n_sup:], S.weight_dict)
+        loss.backward()
+        for v in sd.values():
+            if v.requires_grad:
+                v.grad = None
+        reps += 1
+    el = time.time() - t0
+    return {"value": round(reps * n_unsup / el, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "%d step(s) of %d clips + %d labelled pair(s): oracle teacher fwd + decode + filter + student "
+                      "fwd/bwd (no optimizer), torch-CPU fp32, %d threads" % (reps, n_unsup, n_sup, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips", type=int, default=32, help="unlabelled clips per GPU per step")
+    ap.add_argument("--sup", type=int, default=8, help="labelled pairs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from spot_amd import lib, ops
+    from spot_amd.tensordict import TensorDict
+    lib.load()
+    rank, world, local = build_world(args)
+    assert world == args.gpus, "launch with torchrun --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus)
+    S, trainer, data_sup, data_unsup, mid = build_job(args, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        return trainer.train_iteration(i, TensorDict(data_sup), TensorDict(data_unsup), mid)
+
+    for i in range(args.warmup):
+        step(i)
+    timer = None
+    if not args.no_kernel_timing:
+        timer = ops.TIMER = ops.KernelTimer()
+    skipped0 = trainer.skipped
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    el = time.perf_counter() - t0
+    ops.TIMER = None
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    done = args.steps - (trainer.skipped - skipped0)
+
+    if rank == 0:
+        roofline = None
+        kernels = {}
+        if timer is not None:
+            agg = timer.summary()
+            for k, a in agg.items():
+                kernels[k] = {"launches": a["launches"], "ms_total": round(a["ms"], 3),
+                              "tflops": round(a["work"] / (a["ms"] * 1e-3) / 1e12, 2) if a["ms"] > 0 else None}
+            dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            a = dom[1]
+            ach = a["work"] / (a["ms"] * 1e-3) / 1e12
+            roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches": a["launches"], "avg_us": round(a["ms"] * 1e3 / a["launches"], 2),
+                        "flops_per_launch": a["work"] / a["launches"]}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args)
+        line = {
+            "metric": "tracked frames/sec (fwd-bwd pseudo-labelling + train step)",
+            "value": round(done * args.clips * world / el, 3), "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: %d clips x 3 frames per GPU per step; teacher pseudo-label + decode + "
+                                   "filter + compaction + student fwd/bwd/AdamW on %d labelled + %d pseudo-labelled "
+                                   "pairs (TransT ResNet-50, 128^2 template / 256^2 search, fp32, dropout 0)"
+                                   % (args.clips, args.sup, args.clips),
+                       "clips_per_gpu": args.clips, "sup_pairs_per_gpu": args.sup, "skipped_steps": args.steps - done,
+                       "parallelism": "dp%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

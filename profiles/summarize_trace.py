@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Per-kernel statistics of the STEADY-STATE steps of a rocprofv3 --kernel-trace CSV.
+
+rocprofv3 --stats aggregates the whole process, which for bench.py is dominated by MIOpen's one-off
+algorithm search during the warm-up steps.  This script keeps only the dispatches between the decode
+kernel of step (last - N) and the decode kernel of the last step (N whole steps) and prints the same
+columns as the --stats summary.
+
+usage: summarize_trace.py <kernel_trace.csv> <n_steps> [out.csv]
+"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z0-9_:<>, ]+?)\(", name)
+    return (m.group(1) if m else name)[:96]
+
+
+def main():
+    path, n = sys.argv[1], int(sys.argv[2])
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [int(r["Start_Timestamp"]) for r in rows if "decode_filter_kernel<true" in r["Kernel_Name"]]
+    assert len(marks) > n, "need more than %d decode launches, found %d" % (n, len(marks))
+    t0, t1 = marks[-n - 1], marks[-1]
+    agg = defaultdict(lambda: [0, 0, 10 ** 18, 0])
+    for r in rows:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if t0 <= s < t1:
+            a = agg[short(r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += e - s
+            a[2] = min(a[2], e - s)
+            a[3] = max(a[3], e - s)
+    wall = t1 - t0
+    busy = sum(a[1] for a in agg.values())
+    out = [("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")]
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        out.append((k, a[0], a[1], round(a[1] / a[0], 1), round(100.0 * a[1] / busy, 2), a[2], a[3]))
+    w = csv.writer(open(sys.argv[3], "w", newline="")) if len(sys.argv) > 3 else None
+    print("# window: %d steps, wall %.3f ms/step, kernel-busy %.3f ms/step (%.1f%% of wall)"
+          % (n, wall / n / 1e6, busy / n / 1e6, 100.0 * busy / wall))
+    for row in out:
+        if w:
+            w.writerow(row)
+    for row in out[:40]:
+        print("%-96s %7s %14s %12s %7s" % row[:5])
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,12 @@ missing or a symbol cannot be resolved, importing the product ops fails loudly.
 import ctypes as C
 import os
 
+# PyTorch ships its own HIP runtime (same soname as the system one).  It must be the first one
+# mapped into the process so that the kernels launched from this library and torch's allocator /
+# streams share a single runtime and device context; loading the system runtime first leaves
+# torch without a device.
+import torch  # noqa: F401  (side effect: loads torch's libamdhip64)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspot_hip.so")
 

@@ -18,6 +18,33 @@ def _st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (used by bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.records = []          # (key, work, start_event, end_event)
+
+    def run(self, key, work, launch):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        launch()
+        e.record()
+        self.records.append((key, work, s, e))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, work, s, e in self.records:
+            a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "work": 0.0})
+            a["launches"] += 1
+            a["ms"] += s.elapsed_time(e)
+            a["work"] += work
+        return agg
+
+
+TIMER = None   # set to a KernelTimer to time gemm / attention launches
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -226,7 +253,11 @@ def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None,
     d.ldmask = ldmask
     d.residual = residual.data_ptr() if residual is not None else None
     d.ldres, d.strideRes = ldres, strideRes
-    lib.call("spot_gemm_f32", C.byref(d), _st())
+    if TIMER is not None:
+        TIMER.run("gemm_%s%s" % ("t" if transA else "n", "n" if transB else "t"), 2.0 * M * N * K * batch,
+                  lambda: lib.call("spot_gemm_f32", C.byref(d), _st()))
+    else:
+        lib.call("spot_gemm_f32", C.byref(d), _st())
     return Cout
 
 
@@ -390,8 +421,12 @@ def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, ou
     if out is None:
         out = torch.empty((B * Lq, nhead * dh), dtype=torch.float32, device=dev)
     lse = torch.empty((B, nhead, Lq), dtype=torch.float32, device=dev) if want_lse else None
-    lib.call("spot_mha_fwd_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), out.stride(0), _p(lse), _p(kpm),
-             B, Lq, Lk, nhead, dh, 1.0 / math.sqrt(dh), _st())
+    launch = lambda: lib.call("spot_mha_fwd_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), out.stride(0), _p(lse),
+                              _p(kpm), B, Lq, Lk, nhead, dh, 1.0 / math.sqrt(dh), _st())
+    if TIMER is not None:
+        TIMER.run("mha_fwd", 4.0 * B * nhead * Lq * Lk * dh, launch)
+    else:
+        launch()
     return out, lse
 
 
