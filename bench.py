@@ -43,9 +43,14 @@ def build_job(args, rank):
     from spot_amd.trainer import LTRSparseTrainer
     from spot_amd.transt import transt_resnet50
 
+    if os.environ.get("SPOT_CUDNN_BENCH", "0") == "1":
+        torch.backends.cudnn.benchmark = True
     S = Settings(device="cuda", dropout=0.0, batch_size_sup=args.sup, batch_size_unsup=args.clips)
     stu = det_fill_(transt_resnet50(Settings(device="cpu", dropout=0.0)), 0).cuda()
     tea = det_fill_(transt_resnet50(Settings(device="cpu", dropout=0.0)), 0).cuda()
+    if os.environ.get("SPOT_CHANNELS_LAST", "0") == "1":
+        stu.backbone.to(memory_format=torch.channels_last)
+        tea.backbone.to(memory_format=torch.channels_last)
     stu._spot_arena = ParamArena(stu)
     tea._spot_arena = ParamArena(tea)
     actor = TranstSparseActor(S, stu, tea, transt_loss(S))

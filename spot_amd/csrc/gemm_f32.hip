@@ -11,9 +11,8 @@
 //   B: "NK" = B[n*ldb + k]   (an nn.Linear weight)  or "KN" = B[k*ldb + n]
 // Tiling: 128x128x32 per 256-thread workgroup, 4 waves as 2x2, each wave a 2x2
 // grid of 32x32 MFMA tiles (64 accumulator VGPRs).  Tiles are staged
-// global -> registers -> LDS, double-buffered with one barrier per k-tile: the
-// next tile's global loads are issued before the 64 MFMAs of the current one,
-// the LDS writes after them.  LDS keeps the operand's own storage order
+// global -> registers -> LDS: the next tile's global loads are issued before the
+// 64 MFMAs of the current one, the LDS writes after them.  LDS keeps the operand's own storage order
 // (k-contiguous rows padded to 36 floats for conflict-free 16-byte fragment
 // reads; m/n-contiguous rows read with 4-byte reads), so no transposes happen
 // anywhere.  Within an 8-wide k group lane half h takes k = 4h..4h+3: the
@@ -30,6 +29,7 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int KPAD = BK + 4;    // k-contiguous LDS row stride (floats)
 constexpr int MPAD = BM + 4;    // m/n-contiguous LDS row stride (floats)
 constexpr int TILE_F = 128 * KPAD;  // floats per operand tile buffer (>= 32*MPAD)
+constexpr int CPAD = BN + 4;     // row stride of the epilogue's C staging tile (64 x CPAD floats <= 2*TILE_F)
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -45,6 +45,7 @@ struct GemmArgs {
     int relu;
     const float* mask; long ldmask;   // multiply by (mask[m][n] > 0)
     const float* residual; long ldres; long strideRes;
+    int cvec;                         // every epilogue operand allows 16-byte accesses
 };
 
 template <int LAYOUT_KCONTIG, bool ALIGNED>
@@ -105,10 +106,10 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int g, in
 }
 
 template <int LA, int LB, bool ALIGNED>   // LA: 1 = MK (k-contiguous), 0 = KM;  LB: 1 = NK, 0 = KN
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
-    auto As = [&](int buf) { return lds + buf * TILE_F; };
-    auto Bs = [&](int buf) { return lds + (2 + buf) * TILE_F; };
+__global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE_F];
+    float* const As = lds;
+    float* const Bs = lds + TILE_F;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
@@ -146,25 +147,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         load_tile<LB, ALIGNED>(B + seg * g.segB, g.ldb, n0, kin, g.N, min(g.kseg, g.K - seg * g.kseg), sb, tid);
     };
 
+    // One LDS buffer per operand (36.9 KB per workgroup, so three workgroups share a CU and the
+    // prologue / epilogue of one hides behind the matrix work of the others).  The next tile's
+    // global loads are in flight during the 64 MFMAs of the current tile and land in LDS between
+    // two barriers.
     if (kt0 < kt1) {
         fetch(kt0);
-        store_tile<LA>(As(0), sa, tid);
-        store_tile<LB>(Bs(0), sb, tid);
+        store_tile<LA>(As, sa, tid);
+        store_tile<LB>(Bs, sb, tid);
     }
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
         const bool more = kt + 1 < kt1;
         if (more) fetch(kt + 1);
-        const float* as = As(cur);
-        const float* bs = Bs(cur);
 #pragma unroll
         for (int gk = 0; gk < BK / 8; ++gk) {
             float4 a[2], b[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) a[t] = read_frag<LA>(as, wm * 64 + t * 32 + l31, gk, h);
+            for (int t = 0; t < 2; ++t) a[t] = read_frag<LA>(As, wm * 64 + t * 32 + l31, gk, h);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) b[u] = read_frag<LB>(bs, wn * 64 + u * 32 + l31, gk, h);
+            for (int u = 0; u < 2; ++u) b[u] = read_frag<LB>(Bs, wn * 64 + u * 32 + l31, gk, h);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -175,37 +177,112 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
                 }
         }
-        if (more) {
-            store_tile<LA>(As(cur ^ 1), sa, tid);
-            store_tile<LB>(Bs(cur ^ 1), sb, tid);
-        }
         __syncthreads();
+        if (more) {
+            store_tile<LA>(As, sa, tid);
+            store_tile<LB>(Bs, sb, tid);
+            __syncthreads();
+        }
     }
 
-    // epilogue: accumulator element e of tile (t,u): row = (e&3) + 8*(e>>2) + 4h, col = lane&31
+    // epilogue.  Per-lane dword stores of the accumulator layout (32 floats per row segment) are
+    // store-issue bound, so the tile is transposed through LDS (free after the k loop) and leaves
+    // the chip as 16-byte stores of whole 512-byte rows; bias / row-bias / mask / residual are
+    // read the same way.  Accumulator element e of tile (t,u): row (e&3)+8*(e>>2)+4h, col lane&31.
+    float* Cs = lds;
     float* C = g.C + zb * g.strideC;
-    const float* res = (g.residual && zs == 0) ? g.residual + zb * g.strideRes : nullptr;
-    const float* rowbias = zs == 0 ? g.rowbias : nullptr;
+    const bool first = zs == 0;                      // additive terms enter once under split-K
+    const float* res = (g.residual && first) ? g.residual + zb * g.strideRes : nullptr;
+    const float* rowbias = first ? g.rowbias : nullptr;
+    const float* bias = first ? g.bias : nullptr;
+    const int c4 = (tid & 31) << 2;
+    const int n = n0 + c4;
+    const bool full = g.cvec && n + 3 < g.N;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && g.splitk == 1 && n < g.N) {
+        if (full) bv = *reinterpret_cast<const float4*>(bias + n);
+        else {
+            bv.x = bias[n];
+            if (n + 1 < g.N) bv.y = bias[n + 1];
+            if (n + 2 < g.N) bv.z = bias[n + 2];
+            if (n + 3 < g.N) bv.w = bias[n + 3];
+        }
+    }
+    // the staging tile holds 64 rows at a time: rows of the wm = 0 waves first, then wm = 1
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+        if (wm == half) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int n = n0 + wn * 64 + u * 32 + l31;
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        Cs[(t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CPAD + wn * 64 + u * 32 + l31] = acc[t][u][e];
+        }
+        __syncthreads();
+        const int mh = m0 + half * 64;
+        if (g.splitk > 1) {
+            // split-K partial sums: one dword per lane, 64 consecutive floats per wave-instruction
+            // (the shape float atomics run at full rate in)
+            const int col = tid & 127, nn = n0 + col;
+            if (nn < g.N) {
+                const float b1 = bias ? bias[nn] : 0.f;
+                for (int i = 0; i < 32; ++i) {
+                    const int row = i * 2 + (tid >> 7), m = mh + row;
+                    if (m >= g.M) break;
+                    float x = Cs[row * CPAD + col] * g.alpha + b1;
+                    if (rowbias) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + nn];
+                    if (res) x += res[(long)m * g.ldres + nn];
+                    atomicAdd(C + (long)m * g.ldc + nn, x);
+                }
+            }
+            continue;
+        }
         if (n >= g.N) continue;
-        const float bv = (g.bias && zs == 0) ? g.bias[n] : 0.f;
+#pragma unroll 4
+        for (int i = 0; i < 8; ++i) {
+            const int row = i * 8 + (tid >> 5);
+            const int m = mh + row;
+            if (m >= g.M) break;
+            float4 v = *reinterpret_cast<const float4*>(Cs + row * CPAD + c4);
+            v.x = v.x * g.alpha + bv.x; v.y = v.y * g.alpha + bv.y; v.z = v.z * g.alpha + bv.z; v.w = v.w * g.alpha + bv.w;
+            float* cp = C + (long)m * g.ldc + n;
+            if (full) {
+                if (rowbias) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(rowbias + (long)(m % g.rb_rows) * g.ldrb + n);
+                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                }
+                if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (g.mask) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(g.mask + (long)m * g.ldmask + n);
+                    v.x = k4.x > 0.f ? v.x : 0.f; v.y = k4.y > 0.f ? v.y : 0.f;
+                    v.z = k4.z > 0.f ? v.z : 0.f; v.w = k4.w > 0.f ? v.w : 0.f;
+                }
+                if (res) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(res + (long)m * g.ldres + n);
+                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                }
+                if (g.accumulate) {
+                    float4 o = *reinterpret_cast<float4*>(cp);
+                    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                    *reinterpret_cast<float4*>(cp) = o;
+                } else {
+                    *reinterpret_cast<float4*>(cp) = v;
+                }
+            } else {
+                float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m >= g.M) continue;
-                float v = acc[t][u][e] * g.alpha + bv;
-                if (rowbias) v += rowbias[(long)(m % g.rb_rows) * g.ldrb + n];
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (g.mask) v = g.mask[(long)m * g.ldmask + n] > 0.f ? v : 0.f;
-                if (res) v += res[(long)m * g.ldres + n];
-                float* cp = C + (long)m * g.ldc + n;
-                if (g.splitk > 1) atomicAdd(cp, v);
-                else if (g.accumulate) *cp += v;
-                else *cp = v;
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j >= g.N) break;
+                    float x = vv[j];
+                    if (rowbias) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + n + j];
+                    if (g.relu) x = fmaxf(x, 0.f);
+                    if (g.mask) x = g.mask[(long)m * g.ldmask + n + j] > 0.f ? x : 0.f;
+                    if (res) x += res[(long)m * g.ldres + n + j];
+                    if (g.accumulate) cp[j] += x;
+                    else cp[j] = x;
+                }
             }
         }
     }
@@ -255,6 +332,10 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
                    (a.strideB % 4 == 0) && (a.segA % 4 == 0) && (a.segB % 4 == 0);
     aligned = aligned && (ta ? (a.K % 4 == 0 && a.kseg % 4 == 0) : (a.M % 4 == 0));
     aligned = aligned && (tb ? (a.K % 4 == 0 && a.kseg % 4 == 0) : (a.N % 4 == 0));
+    a.cvec = al(a.C) && a.ldc % 4 == 0 && a.strideC % 4 == 0 && a.N % 4 == 0 &&
+             (!a.bias || al(a.bias)) && (!a.rowbias || (al(a.rowbias) && a.ldrb % 4 == 0)) &&
+             (!a.mask || (al(a.mask) && a.ldmask % 4 == 0)) &&
+             (!a.residual || (al(a.residual) && a.ldres % 4 == 0 && a.strideRes % 4 == 0));
     if (ta && tb) launch<1, 1>(a, d->batch, aligned, stream);
     else if (ta && !tb) launch<1, 0>(a, d->batch, aligned, stream);
     else if (!ta && tb) launch<0, 1>(a, d->batch, aligned, stream);

@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on one MI355X (HIP-event timed, random data).
+
+    python tools/microbench.py gemm | mha | xcorr | norm | all
+"""
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from spot_amd import lib, ops  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def r(*shape):
+    return torch.rand(*shape, device="cuda") * 2 - 1
+
+
+def bench_gemm():
+    print("== gemm (fp32 MFMA, peak 157.3 TF)")
+    B = 40
+    Ms, Mt = B * 1024, B * 256
+    cases = []
+    for M in (Ms, Mt):
+        cases += [("fwd  in-proj   ", M, 768, 256, False, False, dict(rowbias=True)),
+                  ("fwd  out-proj  ", M, 256, 256, False, False, dict(residual=True, bias=True)),
+                  ("fwd  ffn1      ", M, 2048, 256, False, False, dict(relu=True, bias=True)),
+                  ("fwd  ffn2      ", M, 256, 2048, False, False, dict(residual=True, bias=True)),
+                  ("dgrad in-proj  ", M, 256, 768, False, True, {}),
+                  ("dgrad ffn2+mask", M, 2048, 256, False, True, dict(mask=True)),
+                  ("dgrad ffn1     ", M, 256, 2048, False, True, {}),
+                  ("wgrad ffn1     ", 2048, 256, M, True, True, dict(splitk=True)),
+                  ("wgrad ffn2     ", 256, 2048, M, True, True, dict(splitk=True)),
+                  ("wgrad proj     ", 256, 256, M, True, True, dict(splitk=True)),
+                  ("wgrad in-proj  ", 768, 256, M, True, True, dict(splitk=True))]
+    cases.append(("fwd  input_proj", 1024, 256, 1024, True, False, dict(batch=B)))
+    for name, M, N, K, ta, tb, opt in cases:
+        batch = opt.get("batch", 1)
+        A = r(batch, K, M) if ta else r(batch, M, K)
+        Bm = r(K, N) if tb else r(N, K)
+        Cc = torch.zeros(batch, M, N, device="cuda")
+        kw = {}
+        if opt.get("bias"):
+            kw["bias"] = r(N)
+        if opt.get("rowbias"):
+            kw.update(rowbias=r(1024, N), rb_rows=1024, ldrb=N)
+        if opt.get("relu"):
+            kw["relu"] = True
+        if opt.get("residual"):
+            kw.update(residual=r(M, N), ldres=N)
+        if opt.get("mask"):
+            kw.update(mask=r(M, N), ldmask=N)
+        if opt.get("splitk"):
+            kw.update(splitk=ops._splitk_for(M, N, K), accumulate=True)
+        if batch > 1:
+            kw.update(batch=batch, strideA=M * K, strideC=M * N)
+        t = timeit(lambda: ops.gemm(A, Bm, Cc, M, N, K, transA=ta, transB=tb, **kw))
+        fl = 2.0 * M * N * K * batch
+        print("%s M=%6d N=%5d K=%6d  %8.1f us  %6.1f TF  %s" % (name, M, N, K, t * 1e6, fl / t / 1e12,
+                                                               "sk=%d" % kw["splitk"] if "splitk" in kw else ""))
+
+
+def bench_mha():
+    print("== mha core (fp32 MFMA)")
+    B, H, dh = 40, 8, 32
+    C = H * dh
+    for Lq, Lk in ((1024, 1024), (256, 256), (256, 1024), (1024, 256)):
+        q, k, v = r(B * Lq, C), r(B * Lk, C), r(B * Lk, C)
+        out, lse = ops.mha_core_fwd(q, C, k, C, v, C, B, Lq, Lk, H, dh, None, True)
+        t = timeit(lambda: ops.mha_core_fwd(q, C, k, C, v, C, B, Lq, Lk, H, dh, None, True, out=out))
+        fl = 4.0 * B * H * Lq * Lk * dh
+        do = r(B * Lq, C)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty(B, H, Lq, device="cuda")
+        P = ops._p
+
+        def bwd():
+            lib.call("spot_mha_bwd_f32", P(q), C, P(k), C, P(v), C, P(out), C, P(do), C, P(lse), None, P(delta),
+                     P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, H, dh, 1.0 / math.sqrt(dh), ops._st())
+        tb = timeit(bwd)
+        print("Lq=%4d Lk=%4d  fwd %8.1f us %6.1f TF | bwd %8.1f us %6.1f TF" %
+              (Lq, Lk, t * 1e6, fl / t / 1e12, tb * 1e6, 2.5 * fl / tb / 1e12))
+
+
+def bench_xcorr():
+    print("== groupdw (HBM-bound, 8 TB/s peak)")
+    for B, hx, hz, tag in ((128, 45, 5, "cfg5 384^2"), (128, 29, 5, "ocean 255^2")):
+        Cn = 256
+        xs = [r(B, Cn, hx, hx), r(B, Cn, hx - 2, hx), r(B, Cn, hx, hx - 2)]
+        zs = [r(B, Cn, hz, hz), r(B, Cn, hz - 2, hz), r(B, Cn, hz, hz - 2)]
+        w = r(3)
+        t = timeit(lambda: ops.groupdw(zs, xs, w))
+        ho = hx - hz + 1
+        by = 4.0 * (sum(x.numel() for x in xs) + sum(z.numel() for z in zs) + B * Cn * ho * ho)
+        print("%-12s B=%d  %8.1f us  %7.1f GB/s (%.3f GB)" % (tag, B, t * 1e6, by / t / 1e9, by / 1e9))
+        t = timeit(lambda: ops.xcorr_depthwise(xs[0], zs[0]))
+        by = 4.0 * (xs[0].numel() + zs[0].numel() + B * Cn * ho * ho)
+        print("%-12s single xcorr %8.1f us  %7.1f GB/s" % (tag, t * 1e6, by / t / 1e9))
+
+
+def bench_norm():
+    print("== layernorm / colsum / ema / preprocess (HBM-bound)")
+    rows, C = 40960, 256
+    x, g, b = r(rows, C), r(C), r(C)
+    y, mean, rstd = torch.empty_like(x), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    P = ops._p
+    t = timeit(lambda: lib.call("spot_layernorm_fwd_f32", P(x), P(g), P(b), P(y), P(mean), P(rstd), rows, C, 1e-5, ops._st()))
+    print("ln fwd  %7.1f us %7.1f GB/s" % (t * 1e6, 2 * x.numel() * 4 / t / 1e9))
+    dx, dg, db = torch.empty_like(x), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    t = timeit(lambda: lib.call("spot_layernorm_bwd_f32", P(y), P(x), P(mean), P(rstd), P(g), P(dx), P(dg), P(db), rows, C, ops._st()))
+    print("ln bwd  %7.1f us %7.1f GB/s" % (t * 1e6, 3 * x.numel() * 4 / t / 1e9))
+    t = timeit(lambda: ops.colsum(x, out=dg))
+    print("colsum  %7.1f us %7.1f GB/s" % (t * 1e6, x.numel() * 4 / t / 1e9))
+    n = 23_200_000
+    a, s = r(n), r(n)
+    t = timeit(lambda: ops.ema_lerp_(a, s, 0.998))
+    print("ema     %7.1f us %7.1f GB/s" % (t * 1e6, 12.0 * n / t / 1e9))
+    img = torch.randint(0, 255, (40, 3, 256, 256), dtype=torch.uint8, device="cuda")
+    t = timeit(lambda: ops.preprocess_u8(img, None, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]))
+    print("preproc %7.1f us %7.1f GB/s" % (t * 1e6, 5.0 * img.numel() / t / 1e9))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    lib.load()
+    for name, fn in (("gemm", bench_gemm), ("mha", bench_mha), ("xcorr", bench_xcorr), ("norm", bench_norm)):
+        if what in (name, "all"):
+            fn()
