@@ -195,10 +195,12 @@ int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long ldk, const f
  * x,y [rows,C]; mean,rstd [rows] (NULL to skip).  C multiple of 4, <= 1024. */
 int spot_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                            float* rstd, long rows, int C, float eps, hipStream_t stream);
-/* dx, and dgamma/dbeta ADDED into caller-cleared buffers (either may be NULL). */
+/* dx, dgamma, dbeta (the latter two overwritten; either may be NULL).  ws: workspace of
+ * spot_layernorm_bwd_ws_floats(rows, C) floats holding per-workgroup partial sums. */
+long spot_layernorm_bwd_ws_floats(long rows, int C);
 int spot_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd,
-                           const float* gamma, float* dx, float* dgamma, float* dbeta, long rows, int C,
-                           hipStream_t stream);
+                           const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws, long rows,
+                           int C, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -57,12 +57,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;  dgamma += dy * xhat;  dbeta += dy
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;  dgamma = sum dy * xhat;  dbeta = sum dy
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, long rows,
-                                                     int C) {
+                                                     float* __restrict__ partial, long rows, int C) {
     __shared__ float4 red[2][4][64 * MAXV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
@@ -106,14 +105,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                       rs * (g[i].z - c1 - xh[i].z * c2), rs * (g[i].w - c1 - xh[i].w * c2));
         }
     }
-    if (!dgamma && !dbeta) return;
+    if (!partial) return;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         red[0][wave][lane + 64 * i] = ag[i];
         red[1][wave][lane + 64 * i] = ab[i];
     }
     __syncthreads();
-    // 256 threads: thread t sums the 4 waves' partials of float4 slot t (and t+256..)
+    // per-workgroup partial sums [gridDim.x][2][C]; a second kernel adds them (no atomics: the 2C
+    // destination words would be hit by every workgroup)
+    float4* pg = reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * 2 * C);
     for (int idx = threadIdx.x; idx < nv; idx += 256) {
         float4 a = red[0][0][idx], b = red[1][0][idx];
 #pragma unroll
@@ -122,14 +123,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
             b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
         }
-        if (dgamma) {
-            atomicAdd(dgamma + 4 * idx, a.x); atomicAdd(dgamma + 4 * idx + 1, a.y);
-            atomicAdd(dgamma + 4 * idx + 2, a.z); atomicAdd(dgamma + 4 * idx + 3, a.w);
-        }
-        if (dbeta) {
-            atomicAdd(dbeta + 4 * idx, b.x); atomicAdd(dbeta + 4 * idx + 1, b.y);
-            atomicAdd(dbeta + 4 * idx + 2, b.z); atomicAdd(dbeta + 4 * idx + 3, b.w);
-        }
+        pg[idx] = a;
+        pg[nv + idx] = b;
+    }
+}
+
+// dgamma|dbeta [2C] = sum over the nblk partial rows; 64 columns per workgroup, 4 waves split the rows
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ partial, int nblk, int C2,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (col < C2)
+        for (int r = wave; r < nblk; r += 4) s += partial[(size_t)r * C2 + col];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col < C2) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        const int C = C2 >> 1;
+        if (col < C) { if (dgamma) dgamma[col] = t; }
+        else if (dbeta) dbeta[col - C] = t;
     }
 }
 
@@ -171,19 +185,35 @@ extern "C" int spot_layernorm_fwd_f32(const float* x, const float* gamma, const 
     return SPOT_OK;
 }
 
+static int ln_bwd_grid(long rows) {
+    long grid = (rows + 3) / 4;
+    return (int)(grid > 512 ? 512 : grid);
+}
+
+extern "C" long spot_layernorm_bwd_ws_floats(long rows, int C) { return (long)ln_bwd_grid(rows) * 2 * C; }
+
 extern "C" int spot_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd,
-                                      const float* gamma, float* dx, float* dgamma, float* dbeta, long rows, int C,
-                                      hipStream_t stream) {
-    SPOT_CHECK_ARG(dy && x && mean && rstd && gamma && dx, "layernorm_bwd: null pointer");
+                                      const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws,
+                                      long rows, int C, hipStream_t stream) {
     SPOT_CHECK_ARG(rows >= 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXV, "layernorm_bwd: C=%d must be a multiple of 4, <= %d",
                    C, 256 * MAXV);
-    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0,
+    if (rows == 0) {
+        if (dgamma) (void)hipMemsetAsync(dgamma, 0, C * sizeof(float), stream);
+        if (dbeta) (void)hipMemsetAsync(dbeta, 0, C * sizeof(float), stream);
+        return SPOT_OK;
+    }
+    SPOT_CHECK_ARG(dy && x && mean && rstd && gamma && dx, "layernorm_bwd: null pointer");
+    SPOT_CHECK_ARG(!(dgamma || dbeta) || ws, "layernorm_bwd: dgamma/dbeta need the partial-sum workspace");
+    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)ws) & 15) == 0,
                    "layernorm_bwd: buffers must be 16-byte aligned");
-    if (rows == 0) return SPOT_OK;
-    long grid = (rows + 3) / 4;
-    if (grid > 1024) grid = 1024;
-    ln_bwd_kernel<<<(int)grid, 256, 0, stream>>>(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, C);
+    const int grid = ln_bwd_grid(rows);
+    const bool want = dgamma || dbeta;
+    ln_bwd_kernel<<<grid, 256, 0, stream>>>(dy, x, mean, rstd, gamma, dx, want ? ws : nullptr, rows, C);
     SPOT_CHECK_LAUNCH("layernorm_bwd");
+    if (want) {
+        ln_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, stream>>>(ws, grid, 2 * C, dgamma, dbeta);
+        SPOT_CHECK_LAUNCH("layernorm_bwd(reduce)");
+    }
     return SPOT_OK;
 }
 

@@ -53,9 +53,9 @@ class _AttentionParams(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.zeros_(self.out_proj.bias)
 
-    def forward(self, xq, xkv, pos_q, pos_k, kpm, residual, self_attn):
+    def forward(self, xq, xkv, pos_q, pos_k, kpm, add_residual, self_attn):
         return ops.mha_block(xq, xkv, pos_q, pos_k, self.in_proj_weight, self.in_proj_bias,
-                             self.out_proj.weight, self.out_proj.bias, kpm, residual, self.num_heads, self_attn)
+                             self.out_proj.weight, self.out_proj.bias, kpm, add_residual, self.num_heads, self_attn)
 
 
 def _ffn(x, l1, l2):
@@ -81,11 +81,11 @@ class FeatureFusionLayer(nn.Module):
             setattr(self, n, _NormParams(d_model))
 
     def forward(self, src1, src2, kpm1=None, kpm2=None, pos_src1=None, pos_src2=None):
-        src1 = self.norm11(self.self_attn1(src1, src1, pos_src1, pos_src1, kpm1, src1, True))
-        src2 = self.norm21(self.self_attn2(src2, src2, pos_src2, pos_src2, kpm2, src2, True))
+        src1 = self.norm11(self.self_attn1(src1, src1, pos_src1, pos_src1, kpm1, True, True))
+        src2 = self.norm21(self.self_attn2(src2, src2, pos_src2, pos_src2, kpm2, True, True))
         # both cross attentions read the post-ECA streams (:223-230)
-        z1 = self.multihead_attn1(src1, src2, pos_src1, pos_src2, kpm2, src1, False)
-        z2 = self.multihead_attn2(src2, src1, pos_src2, pos_src1, kpm1, src2, False)
+        z1 = self.multihead_attn1(src1, src2, pos_src1, pos_src2, kpm2, True, False)
+        z2 = self.multihead_attn2(src2, src1, pos_src2, pos_src1, kpm1, True, False)
         src1 = self.norm12(z1)
         src1 = self.norm13(_ffn(src1, self.linear11, self.linear12))
         src2 = self.norm22(z2)
@@ -107,7 +107,7 @@ class DecoderCFALayer(nn.Module):
         self.norm2 = _NormParams(d_model)
 
     def forward(self, tgt, memory, memory_kpm=None, pos_enc=None, pos_dec=None):
-        tgt = self.norm1(self.multihead_attn(tgt, memory, pos_dec, pos_enc, memory_kpm, tgt, False))
+        tgt = self.norm1(self.multihead_attn(tgt, memory, pos_dec, pos_enc, memory_kpm, True, False))
         return self.norm2(_ffn(tgt, self.linear1, self.linear2))
 
 

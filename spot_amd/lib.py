@@ -58,7 +58,7 @@ SIGNATURES = {
     "spot_mha_bwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64,
                          i32, i32, i32, i32, i32, f32, vp],
     "spot_layernorm_fwd_f32": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
-    "spot_layernorm_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "spot_layernorm_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
 }
 
 _lib = None
@@ -78,6 +78,8 @@ def load():
     lib.spot_version.argtypes = []
     lib.spot_last_error.restype = C.c_char_p
     lib.spot_last_error.argtypes = []
+    lib.spot_layernorm_bwd_ws_floats.restype = i64
+    lib.spot_layernorm_bwd_ws_floats.argtypes = [i64, i32]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.restype = i32

@@ -279,14 +279,15 @@ def linear_fwd(x2, W, bias=None, relu=False, residual=None, rowbias=None, out=No
     return out
 
 
-def linear_dgrad(dy2, W, mask=None, out=None, accumulate=False):
-    """dx[M,K] = dy2[M,N] W[N,K]  (optionally zeroed where mask <= 0, or added into out)."""
+def linear_dgrad(dy2, W, mask=None, out=None, accumulate=False, residual=None):
+    """dx[M,K] = dy2[M,N] W[N,K]  (optionally zeroed where mask <= 0, plus residual, or added into out)."""
     M, N = dy2.shape
     K = W.shape[1]
     if out is None:
         out = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
     gemm(dy2, W, out, M, K, N, transB=True, lda=dy2.stride(0), ldb=W.stride(0), ldc=out.stride(0), mask=mask,
-         ldmask=mask.stride(0) if mask is not None else 0, accumulate=accumulate)
+         ldmask=mask.stride(0) if mask is not None else 0, accumulate=accumulate, residual=residual,
+         ldres=residual.stride(0) if residual is not None else 0)
     return out
 
 
@@ -365,8 +366,7 @@ class FFNFn(torch.autograd.Function):
         dh = linear_dgrad(dz2, W2, mask=h)                  # relu' folded into the epilogue
         dW2 = linear_wgrad(dz2, h)
         db2 = colsum(dz2)
-        dx = dz2.clone()
-        linear_dgrad(dh, W1, out=dx, accumulate=True)        # residual path + FFN path
+        dx = linear_dgrad(dh, W1, residual=dz2)             # FFN path + residual path in one epilogue
         dW1 = linear_wgrad(dh, x2)
         db1 = colsum(dh)
         return dx.view_as(dz), dW1, db1, dW2, db2
@@ -394,10 +394,11 @@ class LayerNormFn(torch.autograd.Function):
         dy2 = _view2d(dy.contiguous())
         rows, Cn = x2.shape
         dx = torch.empty_like(x2)
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(gamma)
+        dg = torch.empty_like(gamma)
+        db = torch.empty_like(gamma)
+        ws = torch.empty((lib.load().spot_layernorm_bwd_ws_floats(rows, Cn),), dtype=torch.float32, device=dy.device)
         lib.call("spot_layernorm_bwd_f32", _p(dy2), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dg), _p(db),
-                 rows, Cn, _st())
+                 _p(ws), rows, Cn, _st())
         return dx.view_as(dy), dg, db, None
 
 
@@ -436,18 +437,20 @@ def _pos_table(pos2, W, b):
 
 
 class MHAFn(torch.autograd.Function):
-    """z = residual + out_proj(MHA(q = xq + pos_q, k = xkv + pos_k, v = xkv)).
+    """z = xq + out_proj(MHA(q = xq + pos_q, k = xkv + pos_k, v = xkv))   (residual optional).
 
     nn.MultiheadAttention as the fusion layers use it (transt_fusion.py:145-149,
     212-214, 223-232) plus the residual add that follows it.  xq [B,Lq,C],
     xkv [B,Lk,C]; pos_q [Rq,C] / pos_k [Rk,C] with R = L (shared by the batch) or
     B*L; kpm [B,Lk] uint8 or None.  Positional terms enter as per-row bias
     tables (pos W^T + b) added in the projection GEMM's epilogue, so x + pos is
-    never materialised.
+    never materialised.  ``add_residual`` adds the query stream xq to the output
+    (every call site of the reference does, :149,214,232); its gradient is then
+    folded into the query-projection dgrad epilogue instead of a separate add.
     """
 
     @staticmethod
-    def forward(ctx, xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, residual, nhead, self_attn):
+    def forward(ctx, xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn):
         B, Lq, Cn = xq.shape
         Lk = xkv.shape[1]
         dh = Cn // nhead
@@ -473,11 +476,10 @@ class MHAFn(torch.autograd.Function):
             ldq, ldk, ldv = Cn, 2 * Cn, 2 * Cn
         need_grad = any(ctx.needs_input_grad)
         attn, lse = mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, need_grad)
-        res2 = _view2d(residual.contiguous()) if residual is not None else None
-        z = linear_fwd(attn, out_w, out_b, residual=res2)
+        z = linear_fwd(attn, out_w, out_b, residual=xq2 if add_residual else None)
         if need_grad:
             ctx.save_for_backward(xq2, xkv2, pos_q, pos_k, in_w, out_w, qkv, kv, attn, lse, kpm)
-            ctx.dims = (B, Lq, Lk, Cn, nhead, dh, self_attn, residual is not None)
+            ctx.dims = (B, Lq, Lk, Cn, nhead, dh, self_attn, bool(add_residual))
         return z.view(B, Lq, Cn)
 
     @staticmethod
@@ -499,7 +501,7 @@ class MHAFn(torch.autograd.Function):
                      _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
                      _p(dqkv), 3 * Cn, _p(dqkv[:, Cn:]), 3 * Cn, _p(dqkv[:, 2 * Cn:]), 3 * Cn,
                      B, Lq, Lk, nhead, dh, scale, _st())
-            dxq = linear_dgrad(dqkv, in_w)
+            dxq = linear_dgrad(dqkv, in_w, residual=dz2 if has_res else None)
             dxkv = None
             linear_wgrad(dqkv, xq2, out=d_in_w, accumulate=True)
             colsum(dqkv, out=d_in_b)
@@ -514,7 +516,7 @@ class MHAFn(torch.autograd.Function):
                      _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
                      _p(dq), Cn, _p(dkv), 2 * Cn, _p(dkv[:, Cn:]), 2 * Cn,
                      B, Lq, Lk, nhead, dh, scale, _st())
-            dxq = linear_dgrad(dq, in_w[:Cn])
+            dxq = linear_dgrad(dq, in_w[:Cn], residual=dz2 if has_res else None)
             dxkv = linear_dgrad(dkv, in_w[Cn:])
             linear_wgrad(dq, xq2, out=d_in_w[:Cn], accumulate=True)
             linear_wgrad(dkv, xkv2, out=d_in_w[Cn:], accumulate=True)
@@ -525,13 +527,12 @@ class MHAFn(torch.autograd.Function):
             dk_sum = dkv[:, :Cn].reshape(-1, Rk, Cn).sum(0) if Rk != dkv.shape[0] else dkv[:, :Cn]
             linear_wgrad(dq_sum.contiguous(), pos_q, out=d_in_w[:Cn], accumulate=True)
             linear_wgrad(dk_sum.contiguous(), pos_k, out=d_in_w[Cn:2 * Cn], accumulate=True)
-        dres = dz if has_res else None
         if self_attn:
             # xq and xkv are the same tensor: hand the whole gradient to xq
-            return (dxq.view(B, Lq, Cn), None, None, None, d_in_w, d_in_b, d_out_w, d_out_b, None, dres, None, None)
+            return (dxq.view(B, Lq, Cn), None, None, None, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None, None)
         return (dxq.view(B, Lq, Cn), dxkv.view(B, Lk, Cn), None, None, d_in_w, d_in_b, d_out_w, d_out_b, None,
-                dres, None, None)
+                None, None, None)
 
 
-def mha_block(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, residual, nhead, self_attn):
-    return MHAFn.apply(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, residual, nhead, self_attn)
+def mha_block(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn):
+    return MHAFn.apply(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn)

@@ -310,7 +310,7 @@ def test_mha_block_golden(ops, golden):
         xk, pk = (xq, pq) if self_attn else (a("xk", Lk), a("pk", Lk))
         kpm = G(g["kpm_" + tag].astype(np.uint8))
         with torch.no_grad():
-            o = att(xq, xk, pq.reshape(-1, d), pk.reshape(-1, d), kpm, None, self_attn)
+            o = att(xq, xk, pq.reshape(-1, d), pk.reshape(-1, d), kpm, False, self_attn)
         o = o.transpose(0, 1).cpu().numpy()
         np.testing.assert_allclose(o[::8], g["out_" + tag], rtol=1e-3, atol=2e-5)
         np.testing.assert_allclose(np.linalg.norm(o, axis=-1), g["rownorm_" + tag], rtol=1e-4)
