@@ -45,9 +45,15 @@ def build_job(args, rank):
 
     if os.environ.get("SPOT_CUDNN_BENCH", "0") == "1":
         torch.backends.cudnn.benchmark = True
-    S = Settings(device="cuda", dropout=0.0, batch_size_sup=args.sup, batch_size_unsup=args.clips)
-    stu = det_fill_(transt_resnet50(Settings(device="cpu", dropout=0.0)), 0).cuda()
-    tea = det_fill_(transt_resnet50(Settings(device="cpu", dropout=0.0)), 0).cuda()
+    # the reference's training configuration: dropout 0.1, brightness jitter 0.2 (spot_transt_003.py:80,85)
+    S = Settings(device="cuda", dropout=args.dropout, batch_size_sup=args.sup, batch_size_unsup=args.clips)
+    S.aug_settings["jitter"] = 0.2
+    ops_seed = 1000 + rank
+    from spot_amd import ops as _ops
+    _ops.manual_seed(ops_seed)
+    torch.manual_seed(ops_seed)
+    stu = det_fill_(transt_resnet50(S), 0).cuda()
+    tea = det_fill_(transt_resnet50(S), 0).cuda()
     if os.environ.get("SPOT_CHANNELS_LAST", "0") == "1":
         stu.backbone.to(memory_format=torch.channels_last)
         tea.backbone.to(memory_format=torch.channels_last)
@@ -129,6 +135,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--clips", type=int, default=32, help="unlabelled clips per GPU per step")
     ap.add_argument("--sup", type=int, default=8, help="labelled pairs per GPU per step")
+    ap.add_argument("--dropout", type=float, default=0.1, help="student dropout (reference config: 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -192,8 +199,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg2: %d clips x 3 frames per GPU per step; teacher pseudo-label + decode + "
                                    "filter + compaction + student fwd/bwd/AdamW on %d labelled + %d pseudo-labelled "
-                                   "pairs (TransT ResNet-50, 128^2 template / 256^2 search, fp32, dropout 0)"
-                                   % (args.clips, args.sup, args.clips),
+                                   "pairs (TransT ResNet-50, 128^2 template / 256^2 search, fp32, student dropout %g, "
+                                   "brightness jitter 0.2, teacher in eval mode)"
+                                   % (args.clips, args.sup, args.clips, args.dropout),
                        "clips_per_gpu": args.clips, "sup_pairs_per_gpu": args.sup, "skipped_steps": args.steps - done,
                        "parallelism": "dp%d" % world},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,

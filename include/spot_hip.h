@@ -139,8 +139,8 @@ int spot_groupdw_f32(const float* x11, const float* x12, const float* x21, const
  *             B + s*segB with k counted from 0 again (a reduction that runs over several batch slabs).
  *   splitk > 1: K is split over splitk workgroups that add atomically into C (set accumulate = 1 and
  *             clear C first); not combinable with relu / mask.
- * Epilogue order: v = alpha*acc + bias[n] + rowbias[(m % rb_rows)*ldrb + n]; relu; v = mask[m*ldmask+n] > 0 ? v : 0;
- *                 v += residual[m*ldres + n]; C = v or C += v. */
+ * Epilogue order: v = alpha*acc + bias[n] + rowbias[(m % rb_rows)*ldrb + n]; relu; dropout(drop_p, drop_seed);
+ *                 v = mask[m*ldmask+n] > 0 ? v : 0; v += residual[m*ldres + n]; C = v or C += v. */
 typedef struct spot_gemm_desc {
     const float* A;
     const float* B;
@@ -163,9 +163,17 @@ typedef struct spot_gemm_desc {
     long ldmask;
     const float* residual;
     long ldres, strideRes;
+    float drop_p;        /* dropout after relu and before mask/residual: v = keep ? v/(1-p) : 0; 0 = off */
+    unsigned drop_seed;  /* mask = f(drop_seed, global row z*M + m, column n): see spot_dropout_f32 */
 } spot_gemm_desc;
 
 int spot_gemm_f32(const spot_gemm_desc* desc /* host */, hipStream_t stream);
+
+/* nn.Dropout on a [rows, cols] tensor (transt_fusion.py:124,130-131,178,182,191-196) with a counter-based
+ * mask keep(seed, row, col): out = keep ? x/(1-p) : 0.  The same (seed, row, col) function is used by the GEMM
+ * epilogue, so the backward pass re-applies a forward mask by calling this on the incoming gradient. */
+int spot_dropout_f32(const float* x, float* out, long rows, int cols, float p, unsigned seed,
+                     hipStream_t stream);
 
 /* out[n] += sum_m x[m*ld + n]  (bias gradients); out must be cleared by the caller. */
 int spot_colsum_f32(const float* x, long ld, float* out, long rows, int N, hipStream_t stream);
@@ -176,10 +184,13 @@ int spot_colsum_f32(const float* x, long ld, float* out, long rows, int N, hipSt
  * ltr/models/neck/transt_fusion.py:145-148,212-213,218-219,223-230.  q [B,Lq,nhead*32] with row stride ldq
  * (so q/k/v may be column windows of a packed projection buffer), k,v [B,Lk,nhead*32], out [B,Lq,nhead*32];
  * lse [B,nhead,Lq] (log-sum-exp of the scaled scores, NULL to skip; needed by the backward);
- * key_padding_mask [B,Lk] bytes, non-zero = ignore key, or NULL.  head_dim must be 32. */
+ * key_padding_mask [B,Lk] bytes, non-zero = ignore key, or NULL.  head_dim must be 32.
+ * drop_p > 0: dropout on the attention probabilities (nn.MultiheadAttention(dropout=...), :121,172-175) with a
+ * counter-based mask of (drop_seed, clip, head, query, key); the backward regenerates it from the same seed. */
 int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                      float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B,
-                     int Lq, int Lk, int nhead, int head_dim, float scale, hipStream_t stream);
+                     int Lq, int Lk, int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed,
+                     hipStream_t stream);
 
 /* Gradient of the above w.r.t. q, k, v given d_out.  delta_ws: workspace [B,nhead,Lq] floats.
  * dq is accumulated with atomic adds and is cleared by this call. */
@@ -187,7 +198,10 @@ int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long ldk, const f
                      const float* out, long ldo, const float* d_out, long lddo, const float* lse,
                      const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq,
                      float* dk, long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead,
-                     int head_dim, float scale, hipStream_t stream);
+                     int head_dim, float scale, float drop_p, unsigned drop_seed, hipStream_t stream);
+/* The mask the two calls above use, as bytes [B,nhead,Lq,Lk] (1 = kept); for host-side verification. */
+int spot_mha_dropout_mask(unsigned char* mask, int B, int nhead, int Lq, int Lk, float drop_p,
+                          unsigned drop_seed, hipStream_t stream);
 
 /* ---- LayerNorm ----------------------------------------------------------------- */
 

@@ -44,3 +44,22 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+
+// ---------------------------------------------------------------------------
+// Counter-based dropout mask.  keep(seed, row, col) is a pure function of its
+// arguments, so forward and backward kernels regenerate identical masks without
+// storing them.  p_drop is carried as a 32-bit threshold: keep iff hash >= thr.
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ unsigned spot_mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ unsigned spot_row_key(unsigned seed, unsigned row) { return spot_mix32(row ^ seed); }
+__host__ __device__ __forceinline__ bool spot_keep(unsigned row_key, unsigned col, unsigned thr) {
+    return spot_mix32(col + row_key) >= thr;
+}
+static inline unsigned spot_drop_threshold(float p) {
+    if (p <= 0.f) return 0u;
+    double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
+}

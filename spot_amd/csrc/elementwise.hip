@@ -171,7 +171,40 @@ __global__ __launch_bounds__(256) void giou_bwd_kernel(const float4* __restrict_
     d_b1[i] = make_float4(gx0 + gx1, gy0 + gy1, 0.5f * (gx1 - gx0), 0.5f * (gy1 - gy0));
 }
 
+// out = keep(seed,row,col) ? x / (1-p) : 0 with the mask function the GEMM epilogue uses (row = token row,
+// col = channel), so a backward pass can re-apply the forward's mask to the incoming gradient.
+__global__ __launch_bounds__(256) void dropout_kernel(const float4* __restrict__ x, float4* __restrict__ out, long rows,
+                                                      int cols4, unsigned thr, unsigned seed, float scale) {
+    const long total = rows * cols4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / cols4;
+        const int c = (int)(i - r * cols4) * 4;
+        const unsigned rk = spot_row_key(seed, (unsigned)r);
+        float4 v = x[i];
+        v.x = spot_keep(rk, c, thr) ? v.x * scale : 0.f;
+        v.y = spot_keep(rk, c + 1, thr) ? v.y * scale : 0.f;
+        v.z = spot_keep(rk, c + 2, thr) ? v.z * scale : 0.f;
+        v.w = spot_keep(rk, c + 3, thr) ? v.w * scale : 0.f;
+        out[i] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int spot_dropout_f32(const float* x, float* out, long rows, int cols, float p, unsigned seed,
+                                hipStream_t stream) {
+    SPOT_CHECK_ARG(rows >= 0 && cols > 0 && cols % 4 == 0, "dropout: cols=%d must be a positive multiple of 4", cols);
+    SPOT_CHECK_ARG(p >= 0.f && p < 1.f, "dropout: p=%f outside [0,1)", p);
+    if (rows == 0) return SPOT_OK;
+    SPOT_CHECK_ARG(x && out && (((uintptr_t)x | (uintptr_t)out) & 15) == 0, "dropout: buffers must be non-null and 16-byte aligned");
+    const long total = rows * (cols / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    dropout_kernel<<<grid, 256, 0, stream>>>((const float4*)x, (float4*)out, rows, cols / 4, spot_drop_threshold(p), seed,
+                                             1.f / (1.f - p));
+    SPOT_CHECK_LAUNCH("dropout");
+    return SPOT_OK;
+}
 
 extern "C" int spot_preprocess_u8_f32(const unsigned char* images, const float* scale, const float* mean3,
                                       const float* std3, float* out, int B, int C, int H, int W,

@@ -46,6 +46,7 @@ struct GemmArgs {
     const float* mask; long ldmask;   // multiply by (mask[m][n] > 0)
     const float* residual; long ldres; long strideRes;
     int cvec;                         // every epilogue operand allows 16-byte accesses
+    unsigned drop_thr, drop_seed; float drop_scale;   // dropout after relu, before residual (0 = off)
 };
 
 template <int LAYOUT_KCONTIG, bool ALIGNED>
@@ -254,6 +255,13 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
                     v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                 }
                 if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (g.drop_thr) {
+                    const unsigned rk = spot_row_key(g.drop_seed, (unsigned)(zb * g.M + m));
+                    v.x = spot_keep(rk, n, g.drop_thr) ? v.x * g.drop_scale : 0.f;
+                    v.y = spot_keep(rk, n + 1, g.drop_thr) ? v.y * g.drop_scale : 0.f;
+                    v.z = spot_keep(rk, n + 2, g.drop_thr) ? v.z * g.drop_scale : 0.f;
+                    v.w = spot_keep(rk, n + 3, g.drop_thr) ? v.w * g.drop_scale : 0.f;
+                }
                 if (g.mask) {
                     const float4 k4 = *reinterpret_cast<const float4*>(g.mask + (long)m * g.ldmask + n);
                     v.x = k4.x > 0.f ? v.x : 0.f; v.y = k4.y > 0.f ? v.y : 0.f;
@@ -278,6 +286,8 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
                     float x = vv[j];
                     if (rowbias) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + n + j];
                     if (g.relu) x = fmaxf(x, 0.f);
+                    if (g.drop_thr)
+                        x = spot_keep(spot_row_key(g.drop_seed, (unsigned)(zb * g.M + m)), n + j, g.drop_thr) ? x * g.drop_scale : 0.f;
                     if (g.mask) x = g.mask[(long)m * g.ldmask + n + j] > 0.f ? x : 0.f;
                     if (res) x += res[(long)m * g.ldres + n + j];
                     if (g.accumulate) cp[j] += x;
@@ -321,8 +331,12 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
     a.mask = d->mask; a.ldmask = d->ldmask;
     a.residual = d->residual; a.ldres = d->ldres; a.strideRes = d->strideRes;
     SPOT_CHECK_ARG(a.kseg % BK == 0 || a.kseg >= a.K, "gemm: kseg=%d must be a multiple of %d", a.kseg, BK);
+    SPOT_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p=%f outside [0,1)", d->drop_p);
+    a.drop_thr = spot_drop_threshold(d->drop_p);
+    a.drop_seed = d->drop_seed;
+    a.drop_scale = 1.f / (1.f - d->drop_p);
     if (a.splitk > 1) {
-        SPOT_CHECK_ARG(!a.relu && !a.mask, "gemm: split-K cannot be combined with relu/mask epilogues");
+        SPOT_CHECK_ARG(!a.relu && !a.mask && !a.drop_thr, "gemm: split-K cannot be combined with relu/mask/dropout epilogues");
         SPOT_CHECK_ARG(a.accumulate, "gemm: split-K accumulates atomically into C; zero C and set accumulate=1");
     }
     const int ta = d->transA ? 0 : 1, tb = d->transB ? 0 : 1;   // template arg 1 = k-contiguous

@@ -29,10 +29,16 @@ constexpr int KP = DH + 4;    // padded LDS row (floats)
 
 __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
+// attention-probability dropout: keep(q, key) for (clip, head) stream key sbh; Lq, Lk <= 65536
+__device__ __forceinline__ unsigned attn_stream_key(unsigned seed, unsigned bh) { return spot_mix32(bh * 0x9E3779B1U ^ seed); }
+__device__ __forceinline__ bool attn_keep(unsigned sbh, unsigned q, unsigned key, unsigned thr) {
+    return spot_mix32(((q << 16) | key) ^ sbh) >= thr;
+}
+
 __global__ __launch_bounds__(256) void mha_fwd_kernel(
     const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
     float* __restrict__ O, long ldo, float* __restrict__ LSE, const unsigned char* __restrict__ kpm,
-    int Lq, int Lk, int H, float scale) {
+    int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed, float drop_scale) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * KP];
     auto Ks = [&](int buf) { return lds + buf * 2 * KT * KP; };
     auto Vs = [&](int buf) { return lds + buf * 2 * KT * KP + KT * KP; };
@@ -42,6 +48,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(
     const int q = blockIdx.x * 128 + wave * 32 + l31;
     const bool qok = q < Lq;
     const float c = scale * 1.4426950408889634f;   // scores are kept unscaled; exp2((s - m) * c)
+    const unsigned sbh = attn_stream_key(drop_seed, (unsigned)(b * H + head));
 
     // Q fragment: lane holds Q[q][16h .. 16h+15]
     float qf[16];
@@ -133,6 +140,11 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(
             }
             l_run = l_run * alpha + psum;
             m_run = m_new;
+            if (drop_thr) {   // dropout acts on the normalised probabilities: the row sum above stays undropped
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    s[e] = attn_keep(sbh, (unsigned)q, (unsigned)(key0 + acc_row(e, h)), drop_thr) ? s[e] * drop_scale : 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[e] *= alpha;
             // ---- O^T += V^T P^T   (step e sums keys acc_row(e,0) and acc_row(e,1))
@@ -162,7 +174,8 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(
 
 extern "C" int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                 float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B,
-                                int Lq, int Lk, int nhead, int head_dim, float scale, hipStream_t stream) {
+                                int Lq, int Lk, int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed,
+                                hipStream_t stream) {
     SPOT_CHECK_ARG(q && k && v && out, "mha_fwd: null pointer");
     SPOT_CHECK_ARG(head_dim == DH, "mha_fwd: head_dim=%d unsupported (this build handles 32)", head_dim);
     SPOT_CHECK_ARG(B >= 0 && Lq > 0 && Lk > 0 && nhead > 0, "mha_fwd: bad shape B=%d Lq=%d Lk=%d heads=%d", B, Lq, Lk, nhead);
@@ -170,9 +183,12 @@ extern "C" int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long l
                        (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0,
                    "mha_fwd: operands must be 16-byte aligned with row strides that are multiples of 4");
     SPOT_CHECK_ARG(B <= 65535 && nhead <= 65535, "mha_fwd: B and heads must fit a grid dimension");
+    SPOT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mha_fwd: drop_p=%f outside [0,1)", drop_p);
+    SPOT_CHECK_ARG(drop_p == 0.f || (Lq <= 65536 && Lk <= 65536), "mha_fwd: dropout needs Lq, Lk <= 65536");
     if (B == 0) return SPOT_OK;
     dim3 grid((Lq + 127) / 128, nhead, B);
-    mha_fwd_kernel<<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk, nhead, scale);
+    mha_fwd_kernel<<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk, nhead, scale,
+                                             spot_drop_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
     SPOT_CHECK_LAUNCH("mha_fwd");
     return SPOT_OK;
 }
@@ -218,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
     const float* __restrict__ dO, long lddo, const float* __restrict__ LSE, const float* __restrict__ delta,
     const unsigned char* __restrict__ kpm, float* __restrict__ dQ, long lddq, float* __restrict__ dK, long lddk,
-    float* __restrict__ dV, long lddv, int Lq, int Lk, int H, float scale) {
+    float* __restrict__ dV, long lddv, int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed,
+    float drop_scale) {
     // LDS: 2 x (Q tile, dO tile) [32][QP], 2 x (lse, delta) [32], K tile [128][QP], 4 x dS [32][QP]
     __shared__ __attribute__((aligned(16))) float lds[4 * 32 * QP + 4 * 32 + 128 * QP + 4 * 32 * QP];
     auto Qs = [&](int buf) { return lds + buf * 32 * QP; };
@@ -234,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const int key = key_w0 + l31;
     const float c = scale * 1.4426950408889634f;
     const float inv_scale = 1.f / scale;
+    const unsigned sbh = attn_stream_key(drop_seed, (unsigned)(b * H + head));
 
     const float* Qb = Q + (long)b * Lq * ldq + head * DH;
     const float* Gb = dO + (long)b * Lq * lddo + head * DH;
@@ -307,14 +325,18 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
         const float* qs = Qs(cur);
         const float* gs = Gs(cur);
         // ---- S' = Q K^T - LSE/scale ; dP' = dO V^T - delta      (rows q, cols key)
+        // (with dropout the mask multiplies dO V^T before delta is subtracted, so delta is applied later)
         f32x16 s, dp;
+        float dl[16];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const float4 l4 = *reinterpret_cast<const float4*>(Ls(cur) + 8 * g4 + 4 * h);
             const float4 d4 = *reinterpret_cast<const float4*>(Ds(cur) + 8 * g4 + 4 * h);
             s[4 * g4] = -l4.x; s[4 * g4 + 1] = -l4.y; s[4 * g4 + 2] = -l4.z; s[4 * g4 + 3] = -l4.w;
-            dp[4 * g4] = -d4.x; dp[4 * g4 + 1] = -d4.y; dp[4 * g4 + 2] = -d4.z; dp[4 * g4 + 3] = -d4.w;
+            dl[4 * g4] = d4.x; dl[4 * g4 + 1] = d4.y; dl[4 * g4 + 2] = d4.z; dl[4 * g4 + 3] = d4.w;
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dp[e] = drop_thr ? 0.f : -dl[e];
         {
             float qf[16], gf[16];
 #pragma unroll
@@ -333,8 +355,14 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const float p = kdead ? 0.f : __builtin_amdgcn_exp2f(s[e] * c);
-            s[e] = p;
-            dp[e] = p * dp[e] * scale;
+            if (drop_thr) {
+                const float ms = attn_keep(sbh, (unsigned)(t * 32 + acc_row(e, h)), (unsigned)key, drop_thr) ? drop_scale : 0.f;
+                s[e] = p * ms;                                  // dropped probabilities feed dV
+                dp[e] = p * (dp[e] * ms - dl[e]) * scale;       // dS = P (M dP_drop - delta)
+            } else {
+                s[e] = p;
+                dp[e] = p * dp[e] * scale;
+            }
         }
         // ---- dV += P^T dO ; dK += dS^T Q     (A = accumulator register e, B = row q(e,h) of the LDS tile)
 #pragma unroll
@@ -387,7 +415,7 @@ extern "C" int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long l
                                 const float* out, long ldo, const float* d_out, long lddo, const float* lse,
                                 const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq,
                                 float* dk, long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead,
-                                int head_dim, float scale, hipStream_t stream) {
+                                int head_dim, float scale, float drop_p, unsigned drop_seed, hipStream_t stream) {
     SPOT_CHECK_ARG(q && k && v && out && d_out && lse && delta_ws && dq && dk && dv, "mha_bwd: null pointer");
     SPOT_CHECK_ARG(head_dim == DH, "mha_bwd: head_dim=%d unsupported (this build handles 32)", head_dim);
     SPOT_CHECK_ARG(B >= 0 && Lq > 0 && Lk > 0 && nhead > 0, "mha_bwd: bad shape B=%d Lq=%d Lk=%d heads=%d", B, Lq, Lk, nhead);
@@ -395,6 +423,8 @@ extern "C" int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long l
                        (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)d_out) & 15) == 0,
                    "mha_bwd: operands must be 16-byte aligned with row strides that are multiples of 4");
     SPOT_CHECK_ARG(B <= 65535 && nhead <= 65535, "mha_bwd: B and heads must fit a grid dimension");
+    SPOT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mha_bwd: drop_p=%f outside [0,1)", drop_p);
+    SPOT_CHECK_ARG(drop_p == 0.f || (Lq <= 65536 && Lk <= 65536), "mha_bwd: dropout needs Lq, Lk <= 65536");
     if (B == 0) return SPOT_OK;
     // dQ is accumulated atomically: clear its [B*Lq, nhead*32] window first
     hipError_t e = hipMemset2DAsync(dq, (size_t)lddq * sizeof(float), 0, (size_t)nhead * DH * sizeof(float),
@@ -408,7 +438,33 @@ extern "C" int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long l
     SPOT_CHECK_LAUNCH("mha_bwd(delta)");
     dim3 grid((Lk + 127) / 128, nhead, B);
     mha_bwd_kernel<<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, d_out, lddo, lse, delta_ws, key_padding_mask, dq,
-                                             lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale);
+                                             lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale,
+                                             spot_drop_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
     SPOT_CHECK_LAUNCH("mha_bwd");
+    return SPOT_OK;
+}
+
+
+// The attention dropout mask as bytes [B, nhead, Lq, Lk] (1 = kept): lets a host reference apply the very
+// mask the fused kernels regenerate from (seed, clip, head, query, key).
+namespace {
+__global__ __launch_bounds__(256) void attn_mask_kernel(unsigned char* __restrict__ out, int Lq, int Lk, int BH,
+                                                        unsigned thr, unsigned seed) {
+    const long total = (long)BH * Lq * Lk;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const unsigned key = (unsigned)(i % Lk);
+        const unsigned q = (unsigned)((i / Lk) % Lq);
+        const unsigned bh = (unsigned)(i / ((long)Lk * Lq));
+        out[i] = attn_keep(attn_stream_key(seed, bh), q, key, thr) ? 1 : 0;
+    }
+}
+}  // namespace
+
+extern "C" int spot_mha_dropout_mask(unsigned char* mask, int B, int nhead, int Lq, int Lk, float drop_p,
+                                     unsigned drop_seed, hipStream_t stream) {
+    SPOT_CHECK_ARG(mask && B > 0 && nhead > 0 && Lq > 0 && Lk > 0 && Lq <= 65536 && Lk <= 65536, "mha_dropout_mask: bad arguments");
+    SPOT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mha_dropout_mask: drop_p=%f outside [0,1)", drop_p);
+    attn_mask_kernel<<<2048, 256, 0, stream>>>(mask, Lq, Lk, B * nhead, spot_drop_threshold(drop_p), drop_seed);
+    SPOT_CHECK_LAUNCH("mha_dropout_mask");
     return SPOT_OK;
 }

@@ -9,7 +9,9 @@ constructor arguments, forward signature and state-dict keys
 hold parameters; every arithmetic step is a kernel from libspot_hip.so.
 
 Internally tokens are batch-first [B, L, C] (the reference is [L, B, C]).
-Dropout: the kernels implement the deterministic path (p = 0 / eval()).
+Dropout (train mode): attention-probability dropout inside the fused attention kernels, output and
+FFN-hidden dropouts in the GEMM epilogues, all with counter-based masks that backward regenerates
+from a seed (ops.manual_seed); the random stream differs from torch's, the distribution does not.
 """
 import math
 
@@ -53,13 +55,16 @@ class _AttentionParams(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.zeros_(self.out_proj.bias)
 
-    def forward(self, xq, xkv, pos_q, pos_k, kpm, add_residual, self_attn):
+    def forward(self, xq, xkv, pos_q, pos_k, kpm, add_residual, self_attn, p_out=0.0):
+        """p_out: the nn.Dropout the layer applies to this block's output before the residual add."""
+        p_attn = self.dropout if self.training else 0.0
         return ops.mha_block(xq, xkv, pos_q, pos_k, self.in_proj_weight, self.in_proj_bias,
-                             self.out_proj.weight, self.out_proj.bias, kpm, add_residual, self.num_heads, self_attn)
+                             self.out_proj.weight, self.out_proj.bias, kpm, add_residual, self.num_heads, self_attn,
+                             p_attn, p_out)
 
 
-def _ffn(x, l1, l2):
-    return ops.FFNFn.apply(x, l1.weight, l1.bias, l2.weight, l2.bias)
+def _ffn(x, l1, l2, p=0.0):
+    return ops.FFNFn.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, p)
 
 
 class FeatureFusionLayer(nn.Module):
@@ -79,17 +84,19 @@ class FeatureFusionLayer(nn.Module):
         self.linear22 = _LinearParams(dim_feedforward, d_model)
         for n in ("norm11", "norm12", "norm13", "norm21", "norm22", "norm23"):
             setattr(self, n, _NormParams(d_model))
+        self.dropout = dropout
 
     def forward(self, src1, src2, kpm1=None, kpm2=None, pos_src1=None, pos_src2=None):
-        src1 = self.norm11(self.self_attn1(src1, src1, pos_src1, pos_src1, kpm1, True, True))
-        src2 = self.norm21(self.self_attn2(src2, src2, pos_src2, pos_src2, kpm2, True, True))
+        p = self.dropout if self.training else 0.0      # dropout11..23, dropout1/2 of the reference
+        src1 = self.norm11(self.self_attn1(src1, src1, pos_src1, pos_src1, kpm1, True, True, p))
+        src2 = self.norm21(self.self_attn2(src2, src2, pos_src2, pos_src2, kpm2, True, True, p))
         # both cross attentions read the post-ECA streams (:223-230)
-        z1 = self.multihead_attn1(src1, src2, pos_src1, pos_src2, kpm2, True, False)
-        z2 = self.multihead_attn2(src2, src1, pos_src2, pos_src1, kpm1, True, False)
+        z1 = self.multihead_attn1(src1, src2, pos_src1, pos_src2, kpm2, True, False, p)
+        z2 = self.multihead_attn2(src2, src1, pos_src2, pos_src1, kpm1, True, False, p)
         src1 = self.norm12(z1)
-        src1 = self.norm13(_ffn(src1, self.linear11, self.linear12))
+        src1 = self.norm13(_ffn(src1, self.linear11, self.linear12, p))
         src2 = self.norm22(z2)
-        src2 = self.norm23(_ffn(src2, self.linear21, self.linear22))
+        src2 = self.norm23(_ffn(src2, self.linear21, self.linear22, p))
         return src1, src2
 
 
@@ -105,10 +112,12 @@ class DecoderCFALayer(nn.Module):
         self.linear2 = _LinearParams(dim_feedforward, d_model)
         self.norm1 = _NormParams(d_model)
         self.norm2 = _NormParams(d_model)
+        self.dropout = dropout
 
     def forward(self, tgt, memory, memory_kpm=None, pos_enc=None, pos_dec=None):
-        tgt = self.norm1(self.multihead_attn(tgt, memory, pos_dec, pos_enc, memory_kpm, True, False))
-        return self.norm2(_ffn(tgt, self.linear1, self.linear2))
+        p = self.dropout if self.training else 0.0
+        tgt = self.norm1(self.multihead_attn(tgt, memory, pos_dec, pos_enc, memory_kpm, True, False, p))
+        return self.norm2(_ffn(tgt, self.linear1, self.linear2, p))
 
 
 class Encoder(nn.Module):
@@ -178,9 +187,6 @@ class FeatureFusionNetwork(nn.Module):
 
     def forward_tokens(self, src_temp, src_search, pos_temp, pos_search, kpm_temp=None, kpm_search=None):
         """Token-level entry: src [B,L,C], pos [R,C]; returns hs [B, Ls, C]."""
-        if self.training and self.dropout > 0:
-            raise RuntimeError("spot_amd: dropout > 0 in training mode is not implemented by the HIP kernels; "
-                               "construct the network with dropout=0.0 or call eval()")
         mem_t, mem_s = self.encoder(src_temp, src_search, kpm_temp, kpm_search, pos_temp, pos_search)
         return self.decoder(mem_s, mem_t, kpm_temp, pos_temp, pos_search)
 

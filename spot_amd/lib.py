@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("bias", vp), ("rowbias", vp), ("rb_rows", i32), ("ldrb", i64),
         ("relu", i32), ("mask", vp), ("ldmask", i64),
         ("residual", vp), ("ldres", i64), ("strideRes", i64),
+        ("drop_p", f32), ("drop_seed", C.c_uint),
     ]
 
 
@@ -54,9 +55,11 @@ SIGNATURES = {
     "spot_groupdw_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "spot_gemm_f32": [C.POINTER(GemmDesc), vp],
     "spot_colsum_f32": [vp, i64, vp, i64, i32, vp],
-    "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, vp],
+    "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
     "spot_mha_bwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64,
-                         i32, i32, i32, i32, i32, f32, vp],
+                         i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
+    "spot_mha_dropout_mask": [vp, i32, i32, i32, i32, f32, C.c_uint, vp],
+    "spot_dropout_f32": [vp, vp, i64, i32, f32, C.c_uint, vp],
     "spot_layernorm_fwd_f32": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
     "spot_layernorm_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
 }

@@ -45,6 +45,23 @@ class KernelTimer:
 TIMER = None   # set to a KernelTimer to time gemm / attention launches
 
 
+class _Seeds:
+    """Seeds for the counter-based dropout masks: a base (set by manual_seed, mix the rank in for
+    data-parallel runs) and a per-call counter, so a run is reproducible without device RNG state."""
+    base = 0x5107
+    counter = 0
+
+
+def manual_seed(seed):
+    _Seeds.base = int(seed) & 0xffffffff
+    _Seeds.counter = 0
+
+
+def next_seed():
+    _Seeds.counter += 1
+    return (_Seeds.base * 0x9E3779B1 + _Seeds.counter * 0x85EBCA6B) & 0xffffffff
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -233,7 +250,7 @@ def groupdw(zs, xs, weight):
 def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None, ldc=None, batch=1,
          strideA=0, strideB=0, strideC=0, kseg=0, segA=0, segB=0, splitk=1, alpha=1.0, accumulate=False,
          bias=None, rowbias=None, rb_rows=0, ldrb=0, relu=False, mask=None, ldmask=0, residual=None,
-         ldres=0, strideRes=0):
+         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0):
     """Raw access to spot_gemm_f32; tensors are only used for their base pointers."""
     d = GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
@@ -253,6 +270,7 @@ def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None,
     d.ldmask = ldmask
     d.residual = residual.data_ptr() if residual is not None else None
     d.ldres, d.strideRes = ldres, strideRes
+    d.drop_p, d.drop_seed = drop_p, drop_seed
     if TIMER is not None:
         TIMER.run("gemm_%s%s" % ("t" if transA else "n", "n" if transB else "t"), 2.0 * M * N * K * batch,
                   lambda: lib.call("spot_gemm_f32", C.byref(d), _st()))
@@ -266,8 +284,8 @@ def _view2d(t):
     return t.reshape(-1, t.shape[-1])
 
 
-def linear_fwd(x2, W, bias=None, relu=False, residual=None, rowbias=None, out=None):
-    """y[M,N] = x2[M,K] W[N,K]^T + bias (+ rowbias[m % R]) -> relu -> + residual."""
+def linear_fwd(x2, W, bias=None, relu=False, residual=None, rowbias=None, out=None, drop_p=0.0, drop_seed=0):
+    """y[M,N] = x2[M,K] W[N,K]^T + bias (+ rowbias[m % R]) -> relu -> dropout -> + residual."""
     M, K = x2.shape
     N = W.shape[0]
     if out is None:
@@ -275,11 +293,21 @@ def linear_fwd(x2, W, bias=None, relu=False, residual=None, rowbias=None, out=No
     gemm(x2, W, out, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=out.stride(0), bias=bias, relu=relu,
          rowbias=rowbias, rb_rows=rowbias.shape[0] if rowbias is not None else 0,
          ldrb=rowbias.stride(0) if rowbias is not None else 0,
-         residual=residual, ldres=residual.stride(0) if residual is not None else 0)
+         residual=residual, ldres=residual.stride(0) if residual is not None else 0, drop_p=drop_p,
+         drop_seed=drop_seed)
     return out
 
 
-def linear_dgrad(dy2, W, mask=None, out=None, accumulate=False, residual=None):
+def dropout_apply(x2, p, seed):
+    """keep(seed,row,col) ? x/(1-p) : 0 with the mask function of the GEMM epilogue."""
+    if p <= 0:
+        return x2
+    out = torch.empty_like(x2)
+    lib.call("spot_dropout_f32", _p(x2), _p(out), x2.shape[0], x2.shape[1], float(p), seed, _st())
+    return out
+
+
+def linear_dgrad(dy2, W, mask=None, out=None, accumulate=False, residual=None, alpha=1.0):
     """dx[M,K] = dy2[M,N] W[N,K]  (optionally zeroed where mask <= 0, plus residual, or added into out)."""
     M, N = dy2.shape
     K = W.shape[1]
@@ -287,7 +315,7 @@ def linear_dgrad(dy2, W, mask=None, out=None, accumulate=False, residual=None):
         out = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
     gemm(dy2, W, out, M, K, N, transB=True, lda=dy2.stride(0), ldb=W.stride(0), ldc=out.stride(0), mask=mask,
          ldmask=mask.stride(0) if mask is not None else 0, accumulate=accumulate, residual=residual,
-         ldres=residual.stride(0) if residual is not None else 0)
+         ldres=residual.stride(0) if residual is not None else 0, alpha=alpha)
     return out
 
 
@@ -348,28 +376,34 @@ def linear(x, W, b=None, relu=False):
 
 
 class FFNFn(torch.autograd.Function):
-    """z = x + linear2(relu(linear1(x)))  — the FFN sublayer with its residual
-    (transt_fusion.py:151-152,234-235,240-241), dropout-free."""
+    """z = x + drop(linear2(drop(relu(linear1(x)))))  — the FFN sublayer with its residual and both
+    dropouts (transt_fusion.py:151-152,234-235,240-241).  Dropout masks are regenerated from their
+    seeds in backward; the hidden mask and relu' collapse into one test on the stored activation."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2):
+    def forward(ctx, x, W1, b1, W2, b2, p):
         x2 = _view2d(x.contiguous())
-        h = linear_fwd(x2, W1, b1, relu=True)
-        z = linear_fwd(h, W2, b2, residual=x2)
+        s1, s2 = (next_seed(), next_seed()) if p > 0 else (0, 0)
+        h = linear_fwd(x2, W1, b1, relu=True, drop_p=p, drop_seed=s1)
+        z = linear_fwd(h, W2, b2, residual=x2, drop_p=p, drop_seed=s2)
         ctx.save_for_backward(x2, h, W1, W2)
+        ctx.drop = (p, s2)
         return z.view_as(x)
 
     @staticmethod
     def backward(ctx, dz):
         x2, h, W1, W2 = ctx.saved_tensors
+        p, s2 = ctx.drop
         dz2 = _view2d(dz.contiguous())
-        dh = linear_dgrad(dz2, W2, mask=h)                  # relu' folded into the epilogue
-        dW2 = linear_wgrad(dz2, h)
-        db2 = colsum(dz2)
-        dx = linear_dgrad(dh, W1, residual=dz2)             # FFN path + residual path in one epilogue
+        dzd = dropout_apply(dz2, p, s2)                      # gradient behind the output dropout
+        # h > 0 <=> relu passed and the hidden mask kept: one epilogue test, scaled by 1/(1-p)
+        dh = linear_dgrad(dzd, W2, mask=h, alpha=1.0 / (1.0 - p))
+        dW2 = linear_wgrad(dzd, h)
+        db2 = colsum(dzd)
+        dx = linear_dgrad(dh, W1, residual=dz2)              # FFN path + residual path in one epilogue
         dW1 = linear_wgrad(dh, x2)
         db1 = colsum(dh)
-        return dx.view_as(dz), dW1, db1, dW2, db2
+        return dx.view_as(dz), dW1, db1, dW2, db2, None
 
 
 # ---------------------------------------------------------------------------
@@ -417,13 +451,13 @@ def layer_norm_infer(x, gamma, beta, eps=1e-5):
 # ---------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------
-def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, out=None):
+def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, out=None, drop_p=0.0, drop_seed=0):
     dev = q.device
     if out is None:
         out = torch.empty((B * Lq, nhead * dh), dtype=torch.float32, device=dev)
     lse = torch.empty((B, nhead, Lq), dtype=torch.float32, device=dev) if want_lse else None
     launch = lambda: lib.call("spot_mha_fwd_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), out.stride(0), _p(lse),
-                              _p(kpm), B, Lq, Lk, nhead, dh, 1.0 / math.sqrt(dh), _st())
+                              _p(kpm), B, Lq, Lk, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), drop_seed, _st())
     if TIMER is not None:
         TIMER.run("mha_fwd", 4.0 * B * nhead * Lq * Lk * dh, launch)
     else:
@@ -450,7 +484,8 @@ class MHAFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn):
+    def forward(ctx, xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn,
+                p_attn=0.0, p_out=0.0):
         B, Lq, Cn = xq.shape
         Lk = xkv.shape[1]
         dh = Cn // nhead
@@ -475,11 +510,15 @@ class MHAFn(torch.autograd.Function):
             q, k, v = qkv, kv, kv[:, Cn:]
             ldq, ldk, ldv = Cn, 2 * Cn, 2 * Cn
         need_grad = any(ctx.needs_input_grad)
-        attn, lse = mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, need_grad)
-        z = linear_fwd(attn, out_w, out_b, residual=xq2 if add_residual else None)
+        sa = next_seed() if p_attn > 0 else 0
+        so = next_seed() if p_out > 0 else 0
+        attn, lse = mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, need_grad, drop_p=p_attn,
+                                 drop_seed=sa)
+        z = linear_fwd(attn, out_w, out_b, residual=xq2 if add_residual else None, drop_p=p_out, drop_seed=so)
         if need_grad:
             ctx.save_for_backward(xq2, xkv2, pos_q, pos_k, in_w, out_w, qkv, kv, attn, lse, kpm)
             ctx.dims = (B, Lq, Lk, Cn, nhead, dh, self_attn, bool(add_residual))
+            ctx.drop = (p_attn, sa, p_out, so)
         return z.view(B, Lq, Cn)
 
     @staticmethod
@@ -487,10 +526,12 @@ class MHAFn(torch.autograd.Function):
         xq2, xkv2, pos_q, pos_k, in_w, out_w, qkv, kv, attn, lse, kpm = ctx.saved_tensors
         B, Lq, Lk, Cn, nhead, dh, self_attn, has_res = ctx.dims
         dev = dz.device
+        p_attn, sa, p_out, so = ctx.drop
         dz2 = _view2d(dz.contiguous())
-        dattn = linear_dgrad(dz2, out_w)
-        d_out_w = linear_wgrad(dz2, attn)
-        d_out_b = colsum(dz2)
+        dzd = dropout_apply(dz2, p_out, so)                  # gradient behind the output dropout
+        dattn = linear_dgrad(dzd, out_w)
+        d_out_w = linear_wgrad(dzd, attn)
+        d_out_b = colsum(dzd)
         delta = torch.empty((B, nhead, Lq), dtype=torch.float32, device=dev)
         scale = 1.0 / math.sqrt(dh)
         d_in_w = torch.zeros_like(in_w)
@@ -500,7 +541,7 @@ class MHAFn(torch.autograd.Function):
             lib.call("spot_mha_bwd_f32", _p(qkv), 3 * Cn, _p(qkv[:, Cn:]), 3 * Cn, _p(qkv[:, 2 * Cn:]), 3 * Cn,
                      _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
                      _p(dqkv), 3 * Cn, _p(dqkv[:, Cn:]), 3 * Cn, _p(dqkv[:, 2 * Cn:]), 3 * Cn,
-                     B, Lq, Lk, nhead, dh, scale, _st())
+                     B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _st())
             dxq = linear_dgrad(dqkv, in_w, residual=dz2 if has_res else None)
             dxkv = None
             linear_wgrad(dqkv, xq2, out=d_in_w, accumulate=True)
@@ -515,7 +556,7 @@ class MHAFn(torch.autograd.Function):
             lib.call("spot_mha_bwd_f32", _p(qkv), Cn, _p(kv), 2 * Cn, _p(kv[:, Cn:]), 2 * Cn,
                      _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
                      _p(dq), Cn, _p(dkv), 2 * Cn, _p(dkv[:, Cn:]), 2 * Cn,
-                     B, Lq, Lk, nhead, dh, scale, _st())
+                     B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _st())
             dxq = linear_dgrad(dq, in_w[:Cn], residual=dz2 if has_res else None)
             dxkv = linear_dgrad(dkv, in_w[Cn:])
             linear_wgrad(dq, xq2, out=d_in_w[:Cn], accumulate=True)
@@ -529,10 +570,13 @@ class MHAFn(torch.autograd.Function):
             linear_wgrad(dk_sum.contiguous(), pos_k, out=d_in_w[Cn:2 * Cn], accumulate=True)
         if self_attn:
             # xq and xkv are the same tensor: hand the whole gradient to xq
-            return (dxq.view(B, Lq, Cn), None, None, None, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None, None)
+            return (dxq.view(B, Lq, Cn), None, None, None, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None, None,
+                    None, None)
         return (dxq.view(B, Lq, Cn), dxkv.view(B, Lk, Cn), None, None, d_in_w, d_in_b, d_out_w, d_out_b, None,
-                None, None, None)
+                None, None, None, None, None)
 
 
-def mha_block(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn):
-    return MHAFn.apply(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn)
+def mha_block(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn,
+              p_attn=0.0, p_out=0.0):
+    return MHAFn.apply(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn,
+                       p_attn, p_out)

@@ -284,7 +284,7 @@ def test_mha_core_fwd_bwd(ops, Lq, Lk):
     dog = G(do).view(-1, C)
     P = ops._p
     L.call("spot_mha_bwd_f32", P(qg), C, P(kg), C, P(vg), C, P(out), C, P(dog), C, P(lse), P(kp), P(delta),
-           P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), ops._st())
+           P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), 0.0, 0, ops._st())
     np.testing.assert_allclose(dq.view(B, Lq, C).cpu().numpy(), qc.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(dk.view(B, Lk, C).cpu().numpy(), kc.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(dv.view(B, Lk, C).cpu().numpy(), vc.grad.numpy(), rtol=2e-4, atol=2e-5)
@@ -356,3 +356,101 @@ def test_fusion_network_golden(ops, golden):
                   a("pos_temp", (B, d, ht, ht)), a("pos_search", (B, d, hs, hs))).cpu().numpy()
     np.testing.assert_allclose(out[:, :, ::16, ::8], g["hs_slice"], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(np.linalg.norm(out, axis=-1), g["hs_rownorm"], rtol=1e-4)
+
+
+# --------------------------------------------------------------------------- dropout (train mode)
+def test_dropout_mask_statistics_and_gemm_epilogue(ops):
+    rows, cols, p = 4096, 256, 0.1
+    ones = torch.ones(rows, cols, device=DEV)
+    m = ops.dropout_apply(ones, p, 1234)
+    keep = (m > 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 3e-3
+    assert torch.allclose(m[m > 0], torch.tensor(1 / (1 - p), device=DEV))
+    assert torch.equal(m, ops.dropout_apply(ones, p, 1234))            # pure function of (seed,row,col)
+    assert not torch.equal(m, ops.dropout_apply(ones, p, 1235))
+    # per-row and per-column keep rates are unbiased too
+    assert (m > 0).float().mean(0).sub(1 - p).abs().max().item() < 0.03
+    # GEMM epilogue dropout == dropout applied to the plain GEMM result (relu before, residual after)
+    A, W, b, res = G(det_input("A", (512, 128), 1, -1, 1)), G(det_input("W", (256, 128), 2, -1, 1)), \
+        G(det_input("b", (256,), 3, -1, 1)), G(det_input("r", (512, 256), 4, -1, 1))
+    plain = ops.linear_fwd(A, W, b, relu=True)
+    fused = ops.linear_fwd(A, W, b, relu=True, residual=res, drop_p=0.25, drop_seed=77)
+    assert torch.equal(fused, ops.dropout_apply(plain, 0.25, 77) + res)
+
+
+def test_mha_core_dropout_matches_explicit_mask(ops):
+    from spot_amd import lib as L
+    B, nh, dh, Lq, Lk, p, seed = 2, 4, 32, 96, 160, 0.2, 4242
+    C = nh * dh
+    q, k, v = (det_input(n, (B, L_, C), 3, -2, 2) for n, L_ in (("q", Lq), ("k", Lk), ("v", Lk)))
+    do = det_input("do", (B, Lq, C), 4, -1, 1)
+    mask = torch.empty((B, nh, Lq, Lk), dtype=torch.uint8, device=DEV)
+    L.call("spot_mha_dropout_mask", ops._p(mask), B, nh, Lq, Lk, p, seed, ops._st())
+    mk = mask.cpu().double()
+    assert abs(mk.mean().item() - (1 - p)) < 5e-3
+    qg, kg, vg = G(q).view(-1, C), G(k).view(-1, C), G(v).view(-1, C)
+    out, lse = ops.mha_core_fwd(qg, C, kg, C, vg, C, B, Lq, Lk, nh, dh, None, True, drop_p=p, drop_seed=seed)
+    qc, kc, vc = (T(a).double().requires_grad_() for a in (q, k, v))
+    qh = qc.view(B, Lq, nh, dh).transpose(1, 2) / math.sqrt(dh)
+    kh, vh = kc.view(B, Lk, nh, dh).transpose(1, 2), vc.view(B, Lk, nh, dh).transpose(1, 2)
+    pr = torch.softmax(qh @ kh.transpose(-1, -2), -1) * mk / (1 - p)
+    ref = (pr @ vh).transpose(1, 2).reshape(B, Lq, C)
+    np.testing.assert_allclose(out.view(B, Lq, C).cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    (ref * T(do).double()).sum().backward()
+    dq, dk, dv = torch.empty_like(qg), torch.empty_like(kg), torch.empty_like(vg)
+    delta = torch.empty((B, nh, Lq), device=DEV)
+    P = ops._p
+    L.call("spot_mha_bwd_f32", P(qg), C, P(kg), C, P(vg), C, P(out), C, P(G(do).view(-1, C)), C, P(lse), None, P(delta),
+           P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), p, seed, ops._st())
+    np.testing.assert_allclose(dq.view(B, Lq, C).cpu().numpy(), qc.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dk.view(B, Lk, C).cpu().numpy(), kc.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dv.view(B, Lk, C).cpu().numpy(), vc.grad.numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_ffn_dropout_forward_backward_vs_explicit_masks(ops):
+    M, C, F_, p = 384, 64, 128, 0.1
+    x = det_input("x", (M, C), 1, -1, 1)
+    W1, b1 = det_input("W1", (F_, C), 2, -0.3, 0.3), det_input("b1", (F_,), 3, -0.1, 0.1)
+    W2, b2 = det_input("W2", (C, F_), 4, -0.3, 0.3), det_input("b2", (C,), 5, -0.1, 0.1)
+    dz = det_input("dz", (M, C), 6, -1, 1)
+    ops.manual_seed(99)
+    s1, s2 = ops.next_seed(), ops.next_seed()
+    m1 = ops.dropout_apply(torch.ones(M, F_, device=DEV), p, s1).cpu().double()     # mask * 1/(1-p)
+    m2 = ops.dropout_apply(torch.ones(M, C, device=DEV), p, s2).cpu().double()
+    ops.manual_seed(99)
+    gs = [G(a).requires_grad_() for a in (x, W1, b1, W2, b2)]
+    z = ops.FFNFn.apply(gs[0][None], gs[1], gs[2], gs[3], gs[4], p)[0]
+    (z * G(dz)).sum().backward()
+    cs = [T(a).double().requires_grad_() for a in (x, W1, b1, W2, b2)]
+    h = torch.relu(cs[0] @ cs[1].t() + cs[2]) * m1
+    zr = cs[0] + (h @ cs[3].t() + cs[4]) * m2
+    (zr * T(dz).double()).sum().backward()
+    np.testing.assert_allclose(z.detach().cpu().numpy(), zr.detach().numpy(), rtol=1e-4, atol=1e-5)
+    for g_, c_ in zip(gs, cs):
+        np.testing.assert_allclose(g_.grad.cpu().numpy(), c_.grad.numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_fusion_layer_train_mode_dropout_is_reproducible_and_unbiased(ops):
+    from spot_amd.fusion import FeatureFusionLayer
+    d, nh, ff, B, Lt, Ls = 64, 2, 128, 2, 16, 64
+    layer = _load_det(FeatureFusionLayer(d, nh, ff, 0.1), 14).train()
+    a = lambda n, L_: G(det_input(n, (B, L_, d), 14, -1, 1))
+    s1, s2, p1, p2 = a("s1", Lt), a("s2", Ls), a("p1", Lt)[0], a("p2", Ls)[0]
+
+    def run(seed):
+        ops.manual_seed(seed)
+        x1, x2 = s1.clone().requires_grad_(), s2.clone().requires_grad_()
+        o1, o2 = layer(x1, x2, None, None, p1, p2)
+        (o1.sum() + o2.square().sum()).backward()
+        return o1.detach(), o2.detach(), x1.grad, x2.grad
+
+    r1, r2, r3 = run(5), run(5), run(6)
+    for u, w in zip(r1, r2):
+        assert torch.equal(u, w)
+    assert not torch.equal(r1[1], r3[1])
+    assert all(torch.isfinite(t).all() for t in r1)
+    layer.eval()
+    with torch.no_grad():
+        e1, e2 = layer(s1, s2, None, None, p1, p2)
+    # dropout perturbs but does not bias: the train-mode output stays close to eval on average
+    assert (r1[1] - e2).abs().mean().item() < 0.5 * e2.abs().mean().item()

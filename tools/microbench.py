@@ -90,7 +90,7 @@ def bench_mha():
 
         def bwd():
             lib.call("spot_mha_bwd_f32", P(q), C, P(k), C, P(v), C, P(out), C, P(do), C, P(lse), None, P(delta),
-                     P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, H, dh, 1.0 / math.sqrt(dh), ops._st())
+                     P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, H, dh, 1.0 / math.sqrt(dh), 0.0, 0, ops._st())
         tb = timeit(bwd)
         print("Lq=%4d Lk=%4d  fwd %8.1f us %6.1f TF | bwd %8.1f us %6.1f TF" %
               (Lq, Lk, t * 1e6, fl / t / 1e12, tb * 1e6, 2.5 * fl / tb / 1e12))
