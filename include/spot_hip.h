@@ -216,6 +216,18 @@ int spot_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, c
                            const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws, long rows,
                            int C, hipStream_t stream);
 
+/* Gradients of the two calls above.  d_out [planes, hx-hz+1, wx-wz+1]; dx / dkernel may be NULL to skip. */
+int spot_xcorr_depthwise_bwd_f32(const float* x, const float* kernel, const float* d_out, float* dx,
+                                 float* dkernel, int planes, int hx, int wx, int hz, int wz,
+                                 hipStream_t stream);
+/* dsoftmax_partial [planes,3]: per-plane <d_out, xcorr(x_i, z_i)>; summed over planes it is the gradient w.r.t.
+ * softmax(weight3), from which d weight3 = s * (ds - <s, ds>) (NULL to skip). */
+int spot_groupdw_bwd_f32(const float* x11, const float* x12, const float* x21, const float* z11,
+                         const float* z12, const float* z21, const float* weight3, const float* d_out,
+                         float* dx11, float* dx12, float* dx21, float* dz11, float* dz12, float* dz21,
+                         float* dsoftmax_partial, int planes, int hx, int wx, int hz, int wz,
+                         hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,14 @@ namespace {
 
 constexpr int R = 8;  // output rows per work item
 
+// LDS floats reserved for one staged plane: the plane (+3 alignment shift) plus the rows the last,
+// partial strip of R output rows reads past the end (their results are discarded), 16-byte rounded.
+__host__ __device__ inline int plane_floats(int hx, int wx, int hz) {
+    const int ho = hx - hz + 1;
+    const int rows = ((ho + R - 1) / R) * R + hz - 1;
+    return ((rows > hx ? rows : hx) * wx + 3 + 3) & ~3;
+}
+
 // Stage n floats starting at g (4-byte aligned) into LDS so that element e
 // lands at dst[shift + e], shift = misalignment of g in floats; 16-byte loads
 // for the aligned interior, guarded scalar loads for head and tail.
@@ -41,44 +49,42 @@ __device__ __forceinline__ int stage_plane(const float* __restrict__ g, int n, f
     return shift;
 }
 
-// r[0..R) += correlation of the LDS plane xs (row stride wx) with the HZ x WZ
-// template z (global, workgroup-uniform) at output rows i0.., column col.
+// r[0..R) = correlation of the LDS plane xs (row stride wx) with the HZ x WZ template z (global,
+// workgroup-uniform: the taps arrive through scalar loads) at output rows i0.., column col.
+// The tap-column loop is kept rolled so only one (R+HZ-1)-deep register window is live: ~50 VGPRs,
+// which lets six workgroups (24 waves) share a CU and keeps enough loads in flight to stream HBM.
+// Rows past the plane are never guarded: the LDS plane is over-allocated and those outputs are dropped.
 template <int HZ, int WZ>
-__device__ __forceinline__ void corr_column(const float* xs, int wx, int hx, const float* __restrict__ z, int i0,
-                                            int col, float (&r)[R]) {
-    float zr[HZ * WZ];
-#pragma unroll
-    for (int k = 0; k < HZ * WZ; ++k) zr[k] = z[k];
+__device__ __forceinline__ void corr_column(const float* xs, int wx, const float* __restrict__ z, int i0, int col,
+                                            float (&r)[R]) {
 #pragma unroll
     for (int k = 0; k < R; ++k) r[k] = 0.f;
-#pragma unroll
+    const float* xp = xs + i0 * wx + col;
+#pragma unroll 1
     for (int v = 0; v < WZ; ++v) {
         float xc[R + HZ - 1];
 #pragma unroll
-        for (int k = 0; k < R + HZ - 1; ++k) {
-            const int row = i0 + k;
-            xc[k] = row < hx ? xs[row * wx + col + v] : 0.f;
+        for (int k = 0; k < R + HZ - 1; ++k) xc[k] = xp[k * wx + v];
+#pragma unroll
+        for (int u = 0; u < HZ; ++u) {
+            const float zv = z[u * WZ + v];
+#pragma unroll
+            for (int k = 0; k < R; ++k) r[k] = fmaf(xc[k + u], zv, r[k]);
         }
-#pragma unroll
-        for (int u = 0; u < HZ; ++u)
-#pragma unroll
-            for (int k = 0; k < R; ++k) r[k] = fmaf(xc[k + u], zr[u * WZ + v], r[k]);
     }
 }
 
-// runtime-sized template (any hz, wz): taps read through the scalar/L1 path
-__device__ __forceinline__ void corr_column_rt(const float* xs, int wx, int hx, const float* __restrict__ z, int hz,
-                                               int wz, int i0, int col, float (&r)[R]) {
+// runtime-sized template (any hz, wz)
+__device__ __forceinline__ void corr_column_rt(const float* xs, int wx, const float* __restrict__ z, int hz, int wz,
+                                               int i0, int col, float (&r)[R]) {
 #pragma unroll
     for (int k = 0; k < R; ++k) r[k] = 0.f;
+    const float* xp = xs + i0 * wx + col;
     for (int u = 0; u < hz; ++u)
         for (int v = 0; v < wz; ++v) {
             const float zv = z[u * wz + v];
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const int row = i0 + k + u;
-                r[k] = fmaf(row < hx ? xs[row * wx + col + v] : 0.f, zv, r[k]);
-            }
+            for (int k = 0; k < R; ++k) r[k] = fmaf(xp[(k + u) * wx + v], zv, r[k]);
         }
 }
 
@@ -90,7 +96,7 @@ struct Branch {
 
 // KIND 0: runtime template sizes; KIND 5: Ocean's (5x5, 3x5, 5x3) triple.
 template <int NB, int KIND>
-__global__ __launch_bounds__(256) void groupdw_kernel(Branch b0, Branch b1, Branch b2, const float* __restrict__ weight,
+__global__ __launch_bounds__(256, 6) void groupdw_kernel(Branch b0, Branch b1, Branch b2, const float* __restrict__ weight,
                                                       float* __restrict__ out, int Ho, int Wo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int p = blockIdx.x;
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(256) void groupdw_kernel(Branch b0, Branch b1, Bran
         const int n = br[i].hx * br[i].wx;
         const int sh = stage_plane(br[i].x + (size_t)p * n, n, smem + off, tid);
         xs[i] = smem + off + sh;
-        off += (n + 3 + 3) & ~3;
+        off += plane_floats(br[i].hx, br[i].wx, br[i].hz);
     }
     float sw[3] = {1.f, 0.f, 0.f};
     if (NB == 3) {
@@ -126,11 +132,11 @@ __global__ __launch_bounds__(256) void groupdw_kernel(Branch b0, Branch b1, Bran
         for (int i = 0; i < NB; ++i) {
             const float* z = br[i].z + (size_t)p * br[i].hz * br[i].wz;
             if (KIND == 5) {
-                if (i == 0) corr_column<5, 5>(xs[0], br[0].wx, br[0].hx, z, i0, col, r);
-                if (i == 1) corr_column<3, 5>(xs[1], br[1].wx, br[1].hx, z, i0, col, r);
-                if (i == 2) corr_column<5, 3>(xs[2], br[2].wx, br[2].hx, z, i0, col, r);
+                if (i == 0) corr_column<5, 5>(xs[0], br[0].wx, z, i0, col, r);
+                if (i == 1) corr_column<3, 5>(xs[1], br[1].wx, z, i0, col, r);
+                if (i == 2) corr_column<5, 3>(xs[2], br[2].wx, z, i0, col, r);
             } else {
-                corr_column_rt(xs[i], br[i].wx, br[i].hx, z, br[i].hz, br[i].wz, i0, col, r);
+                corr_column_rt(xs[i], br[i].wx, z, br[i].hz, br[i].wz, i0, col, r);
             }
 #pragma unroll
             for (int k = 0; k < R; ++k) acc[k] = NB == 1 ? r[k] : __fadd_rn(acc[k], __fmul_rn(sw[i], r[k]));
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(256) void groupdw_kernel(Branch b0, Branch b1, Bran
 
 size_t lds_bytes(const Branch* b, int nb) {
     size_t f = 0;
-    for (int i = 0; i < nb; ++i) f += ((size_t)b[i].hx * b[i].wx + 6) & ~(size_t)3;
+    for (int i = 0; i < nb; ++i) f += plane_floats(b[i].hx, b[i].wx, b[i].hz);
     return f * sizeof(float);
 }
 
@@ -181,4 +187,160 @@ extern "C" int spot_groupdw_f32(const float* x11, const float* x12, const float*
         groupdw_kernel<3, 0><<<planes, 256, lds, stream>>>(b[0], b[1], b[2], weight3, out, Ho, Wo);
     SPOT_CHECK_LAUNCH("groupdw");
     return SPOT_OK;
+}
+
+// ===========================================================================
+// Backward of xcorr_depthwise / GroupDW.  With g = dL/dout [planes, Ho, Wo] and
+// s_i = softmax(weight)_i:
+//   dx_i[a,b] = s_i * sum_{u,v} g[a-u, b-v] z_i[u,v]     (full correlation = valid correlation of the
+//                                                          zero-padded g with the flipped template)
+//   dz_i[u,v] = s_i * sum_{i,j} g[i,j] x_i[i+u, j+v]
+//   ds_i      = sum over planes of sum_{u,v} z_i[u,v] * (dz_i[u,v] / s_i)   (= <g, xcorr(x_i, z_i)>)
+// One workgroup per plane: g is staged zero-padded in LDS, the x planes beside it.  dx reuses the
+// forward's register-window column walk; each dz tap is reduced by one wave.  ds is written as a
+// per-plane partial [planes, 3] (summed by the caller) to keep the result order-independent.
+// ===========================================================================
+namespace {
+
+constexpr int GPAD_MAX = 8;   // largest template extent - 1 the padded-g staging supports
+
+__global__ __launch_bounds__(256) void groupdw_bwd_kernel(Branch b0, Branch b1, Branch b2, int nb,
+                                                          const float* __restrict__ weight,
+                                                          const float* __restrict__ g, int Ho, int Wo,
+                                                          float* __restrict__ dx0, float* __restrict__ dx1,
+                                                          float* __restrict__ dx2, float* __restrict__ dz0,
+                                                          float* __restrict__ dz1, float* __restrict__ dz2,
+                                                          float* __restrict__ dsw_partial, int pad, int gp_rows,
+                                                          int gp_cols) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Branch br[3] = {b0, b1, b2};
+    float* dxs[3] = {dx0, dx1, dx2};
+    float* dzs[3] = {dz0, dz1, dz2};
+    // ---- stage: zero-padded g, then the x planes
+    float* gp = smem;
+    for (int i = tid; i < gp_rows * gp_cols; i += 256) gp[i] = 0.f;
+    __syncthreads();
+    const float* gsrc = g + (size_t)p * Ho * Wo;
+    for (int i = tid; i < Ho * Wo; i += 256) {
+        const int r = i / Wo, c = i - r * Wo;
+        gp[(r + pad) * gp_cols + c + pad] = gsrc[i];
+    }
+    int off = (gp_rows * gp_cols + 3) & ~3;
+    float* xs[3];
+    for (int i = 0; i < nb; ++i) {
+        const int n = br[i].hx * br[i].wx;
+        const int sh = stage_plane(br[i].x + (size_t)p * n, n, smem + off, tid);
+        xs[i] = smem + off + sh;
+        off += (n + 6) & ~3;
+    }
+    float sw[3] = {1.f, 0.f, 0.f};
+    if (nb == 3) {
+        const float w0 = weight[0], w1 = weight[1], w2 = weight[2];
+        const float m = fmaxf(w0, fmaxf(w1, w2));
+        const float e0 = expf(w0 - m), e1 = expf(w1 - m), e2 = expf(w2 - m);
+        const float s = e0 + e1 + e2;
+        sw[0] = e0 / s; sw[1] = e1 / s; sw[2] = e2 / s;
+    }
+    __syncthreads();
+    for (int i = 0; i < nb; ++i) {
+        const int hx = br[i].hx, wx = br[i].wx, hz = br[i].hz, wz = br[i].wz;
+        const float* z = br[i].z + (size_t)p * hz * wz;
+        // ---- dx_i: R-row register window down one column of the padded g
+        if (dxs[i]) {
+            float* op = dxs[i] + (size_t)p * hx * wx;
+            const int nstrip = (hx + R - 1) / R;
+            const int o0 = pad - (hz - 1), o1 = pad - (wz - 1);     // origin of this branch inside the padding
+            for (int item = tid; item < nstrip * wx; item += 256) {
+                const int strip = item / wx, col = item - strip * wx, a0 = strip * R;
+                float r[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) r[k] = 0.f;
+                for (int u = 0; u < hz; ++u)
+                    for (int v = 0; v < wz; ++v) {
+                        const float zv = z[(hz - 1 - u) * wz + (wz - 1 - v)];
+#pragma unroll
+                        for (int k = 0; k < R; ++k) r[k] = fmaf(gp[(a0 + k + u + o0) * gp_cols + col + v + o1], zv, r[k]);
+                    }
+#pragma unroll
+                for (int k = 0; k < R; ++k)
+                    if (a0 + k < hx) op[(a0 + k) * wx + col] = sw[i] * r[k];
+            }
+        }
+        // ---- dz_i (and its contribution to ds_i): one wave per tap
+        float ds_acc = 0.f;
+        for (int tap = wave; tap < hz * wz; tap += 4) {
+            const int u = tap / wz, v = tap - u * wz;
+            float acc = 0.f;
+            for (int q = lane; q < Ho * Wo; q += 64) {
+                const int r = q / Wo, c = q - r * Wo;
+                acc = fmaf(gp[(r + pad) * gp_cols + c + pad], xs[i][(r + u) * wx + c + v], acc);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                if (dzs[i]) dzs[i][(size_t)p * hz * wz + tap] = sw[i] * acc;
+                ds_acc = fmaf(z[tap], acc, ds_acc);
+            }
+        }
+        if (dsw_partial && nb == 3) {
+            __shared__ float ds_red[4];
+            if (lane == 0) ds_red[wave] = ds_acc;
+            __syncthreads();
+            if (tid == 0) dsw_partial[(size_t)p * 3 + i] = (ds_red[0] + ds_red[1]) + (ds_red[2] + ds_red[3]);
+            __syncthreads();
+        }
+    }
+}
+
+int launch_bwd(const Branch* b, int nb, const float* weight, const float* g, float** dx, float** dz, float* dsw,
+               int planes, hipStream_t stream) {
+    const int Ho = b[0].hx - b[0].hz + 1, Wo = b[0].wx - b[0].wz + 1;
+    int pad = 0;
+    for (int i = 0; i < nb; ++i) {
+        pad = b[i].hz - 1 > pad ? b[i].hz - 1 : pad;
+        pad = b[i].wz - 1 > pad ? b[i].wz - 1 : pad;
+    }
+    SPOT_CHECK_ARG(pad <= GPAD_MAX, "xcorr backward: template extent %d exceeds %d", pad + 1, GPAD_MAX + 1);
+    int max_hx = 0;
+    for (int i = 0; i < nb; ++i) max_hx = b[i].hx > max_hx ? b[i].hx : max_hx;
+    // rows: every R-strip of dx may read R + hz - 1 rows starting at its origin
+    const int gp_rows = ((max_hx + R - 1) / R) * R + 2 * pad, gp_cols = Wo + 2 * pad;
+    size_t f = ((size_t)gp_rows * gp_cols + 3) & ~(size_t)3;
+    for (int i = 0; i < nb; ++i) f += ((size_t)b[i].hx * b[i].wx + 6) & ~(size_t)3;
+    SPOT_CHECK_ARG(f * sizeof(float) <= 64 * 1024, "xcorr backward: planes of %dx%d do not fit the 64 KB LDS stage", b[0].hx,
+                   b[0].wx);
+    groupdw_bwd_kernel<<<planes, 256, f * sizeof(float), stream>>>(b[0], b[1], b[2], nb, weight, g, Ho, Wo, dx[0], dx[1],
+                                                                  dx[2], dz[0], dz[1], dz[2], dsw, pad, gp_rows, gp_cols);
+    SPOT_CHECK_LAUNCH("xcorr backward");
+    return SPOT_OK;
+}
+
+}  // namespace
+
+extern "C" int spot_xcorr_depthwise_bwd_f32(const float* x, const float* kernel, const float* d_out, float* dx,
+                                            float* dkernel, int planes, int hx, int wx, int hz, int wz,
+                                            hipStream_t stream) {
+    SPOT_CHECK_ARG(planes >= 0 && hx >= hz && wx >= wz && hz > 0 && wz > 0,
+                   "xcorr_depthwise_bwd: bad shape planes=%d x=%dx%d kernel=%dx%d", planes, hx, wx, hz, wz);
+    if (planes == 0) return SPOT_OK;
+    SPOT_CHECK_ARG(x && kernel && d_out && (dx || dkernel), "xcorr_depthwise_bwd: null pointer");
+    Branch b[3] = {{x, kernel, hx, wx, hz, wz}, {}, {}};
+    float* dxs[3] = {dx, nullptr, nullptr};
+    float* dzs[3] = {dkernel, nullptr, nullptr};
+    return launch_bwd(b, 1, nullptr, d_out, dxs, dzs, nullptr, planes, stream);
+}
+
+extern "C" int spot_groupdw_bwd_f32(const float* x11, const float* x12, const float* x21, const float* z11,
+                                    const float* z12, const float* z21, const float* weight3, const float* d_out,
+                                    float* dx11, float* dx12, float* dx21, float* dz11, float* dz12, float* dz21,
+                                    float* dsoftmax_partial, int planes, int hx, int wx, int hz, int wz,
+                                    hipStream_t stream) {
+    SPOT_CHECK_ARG(planes >= 0 && hz >= 3 && wz >= 3 && hx >= hz && wx >= wz,
+                   "groupdw_bwd: bad shape planes=%d x11=%dx%d z11=%dx%d", planes, hx, wx, hz, wz);
+    if (planes == 0) return SPOT_OK;
+    SPOT_CHECK_ARG(x11 && x12 && x21 && z11 && z12 && z21 && weight3 && d_out, "groupdw_bwd: null pointer");
+    Branch b[3] = {{x11, z11, hx, wx, hz, wz}, {x12, z12, hx - 2, wx, hz - 2, wz}, {x21, z21, hx, wx - 2, hz, wz - 2}};
+    float* dxs[3] = {dx11, dx12, dx21};
+    float* dzs[3] = {dz11, dz12, dz21};
+    return launch_bwd(b, 3, weight3, d_out, dxs, dzs, dsoftmax_partial, planes, stream);
 }

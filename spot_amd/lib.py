@@ -53,6 +53,8 @@ SIGNATURES = {
     "spot_box_giou_pair_bwd_f32": [vp, vp, vp, vp, vp, i32, vp],
     "spot_xcorr_depthwise_f32": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "spot_groupdw_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "spot_xcorr_depthwise_bwd_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "spot_groupdw_bwd_f32": [vp] * 15 + [i32, i32, i32, i32, i32, vp],
     "spot_gemm_f32": [C.POINTER(GemmDesc), vp],
     "spot_colsum_f32": [vp, i64, vp, i64, i32, vp],
     "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],

@@ -219,29 +219,69 @@ class GIoUPairFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------
 # depthwise cross-correlation
 # ---------------------------------------------------------------------------
+class XCorrDepthwiseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel):
+        x, kernel = _chk(x.contiguous()), _chk(kernel.contiguous())
+        B, Cn, hx, wx = x.shape
+        _, _, hz, wz = kernel.shape
+        out = torch.empty((B, Cn, hx - hz + 1, wx - wz + 1), dtype=torch.float32, device=x.device)
+        lib.call("spot_xcorr_depthwise_f32", _p(x), _p(kernel), _p(out), B * Cn, hx, wx, hz, wz, _st())
+        ctx.save_for_backward(x, kernel)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, kernel = ctx.saved_tensors
+        B, Cn, hx, wx = x.shape
+        _, _, hz, wz = kernel.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dk = torch.empty_like(kernel) if ctx.needs_input_grad[1] else None
+        lib.call("spot_xcorr_depthwise_bwd_f32", _p(x), _p(kernel), _p(g.contiguous()), _p(dx), _p(dk), B * Cn,
+                 hx, wx, hz, wz, _st())
+        return dx, dk
+
+
 def xcorr_depthwise(x, kernel):
-    """Drop-in for ocean_fusion.xcorr_depthwise (forward)."""
-    _chk(x), _chk(kernel)
-    B, Cn, hx, wx = x.shape
-    _, _, hz, wz = kernel.shape
-    out = torch.empty((B, Cn, hx - hz + 1, wx - wz + 1), dtype=torch.float32, device=x.device)
-    lib.call("spot_xcorr_depthwise_f32", _p(x), _p(kernel), _p(out), B * Cn, hx, wx, hz, wz, _st())
-    return out
+    """Drop-in for ocean_fusion.xcorr_depthwise (differentiable)."""
+    return XCorrDepthwiseFn.apply(x, kernel)
+
+
+class GroupDWFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z11, z12, z21, x11, x12, x21, weight):
+        ts = [_chk(t.contiguous()) for t in (z11, z12, z21, x11, x12, x21, weight)]
+        z11, z12, z21, x11, x12, x21, weight = ts
+        B, Cn, hx, wx = x11.shape
+        _, _, hz, wz = z11.shape
+        assert tuple(x12.shape[2:]) == (hx - 2, wx) and tuple(x21.shape[2:]) == (hx, wx - 2), "branch shapes"
+        assert tuple(z12.shape[2:]) == (hz - 2, wz) and tuple(z21.shape[2:]) == (hz, wz - 2), "branch shapes"
+        out = torch.empty((B, Cn, hx - hz + 1, wx - wz + 1), dtype=torch.float32, device=x11.device)
+        lib.call("spot_groupdw_f32", _p(x11), _p(x12), _p(x21), _p(z11), _p(z12), _p(z21), _p(weight), _p(out),
+                 B * Cn, hx, wx, hz, wz, _st())
+        ctx.save_for_backward(*ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z11, z12, z21, x11, x12, x21, weight = ctx.saved_tensors
+        B, Cn, hx, wx = x11.shape
+        _, _, hz, wz = z11.shape
+        dzs = [torch.empty_like(t) for t in (z11, z12, z21)]
+        dxs = [torch.empty_like(t) for t in (x11, x12, x21)]
+        part = torch.empty((B * Cn, 3), dtype=torch.float32, device=g.device)
+        lib.call("spot_groupdw_bwd_f32", _p(x11), _p(x12), _p(x21), _p(z11), _p(z12), _p(z21), _p(weight),
+                 _p(g.contiguous()), _p(dxs[0]), _p(dxs[1]), _p(dxs[2]), _p(dzs[0]), _p(dzs[1]), _p(dzs[2]),
+                 _p(part), B * Cn, hx, wx, hz, wz, _st())
+        ds = part.sum(0)
+        sw = torch.softmax(weight, 0)
+        dw = sw * (ds - (sw * ds).sum())
+        return dzs[0], dzs[1], dzs[2], dxs[0], dxs[1], dxs[2], dw
 
 
 def groupdw(zs, xs, weight):
-    """Fused GroupDW.forward: softmax(weight)-weighted sum of three depthwise correlations."""
-    z11, z12, z21 = [_chk(t) for t in zs]
-    x11, x12, x21 = [_chk(t) for t in xs]
-    _chk(weight)
-    B, Cn, hx, wx = x11.shape
-    _, _, hz, wz = z11.shape
-    assert tuple(x12.shape[2:]) == (hx - 2, wx) and tuple(x21.shape[2:]) == (hx, wx - 2), "branch shapes"
-    assert tuple(z12.shape[2:]) == (hz - 2, wz) and tuple(z21.shape[2:]) == (hz, wz - 2), "branch shapes"
-    out = torch.empty((B, Cn, hx - hz + 1, wx - wz + 1), dtype=torch.float32, device=x11.device)
-    lib.call("spot_groupdw_f32", _p(x11), _p(x12), _p(x21), _p(z11), _p(z12), _p(z21), _p(weight), _p(out),
-             B * Cn, hx, wx, hz, wz, _st())
-    return out
+    """Fused GroupDW.forward (differentiable): softmax(weight)-weighted sum of three depthwise correlations."""
+    return GroupDWFn.apply(zs[0], zs[1], zs[2], xs[0], xs[1], xs[2], weight)
 
 
 # ---------------------------------------------------------------------------

@@ -454,3 +454,33 @@ def test_fusion_layer_train_mode_dropout_is_reproducible_and_unbiased(ops):
         e1, e2 = layer(s1, s2, None, None, p1, p2)
     # dropout perturbs but does not bias: the train-mode output stays close to eval on average
     assert (r1[1] - e2).abs().mean().item() < 0.5 * e2.abs().mean().item()
+
+
+def test_xcorr_backward_golden(ops, golden):
+    g = golden("g12_xcorr")
+    for tag in ("ocean255", "cfg5"):
+        B, C, hx, hz = [int(v) for v in g["dims_" + tag]]
+        shp_x = [(hx - 2, hx - 2), (hx - 4, hx - 2), (hx - 2, hx - 4)]
+        shp_z = [(hz - 2, hz - 2), (hz - 4, hz - 2), (hz - 2, hz - 4)]
+        xs = [G(det_input("x%d%s" % (i, tag), (B, C) + s, 71, -1, 1)).requires_grad_() for i, s in enumerate(shp_x)]
+        zs = [G(det_input("z%d%s" % (i, tag), (B, C) + s, 71, -1, 1)).requires_grad_() for i, s in enumerate(shp_z)]
+        w = G(np.asarray(g["weight"], np.float32)).requires_grad_()
+        s = ops.groupdw(zs, xs, w)
+        up = G(det_input("g" + tag, tuple(s.shape), 71, -1, 1))
+        (s * up).sum().backward()
+        for i in range(3):
+            np.testing.assert_allclose(xs[i].grad.cpu().numpy(), g["dx%d_%s" % (i, tag)], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(zs[i].grad.cpu().numpy(), g["dz%d_%s" % (i, tag)], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(w.grad.cpu().numpy(), g["dw_" + tag], rtol=1e-3, atol=1e-3)
+    # single correlation, odd shapes, vs torch autograd on the CPU
+    for (B, C, hx, wx, hz, wz) in ((1, 2, 9, 7, 3, 2), (2, 3, 20, 31, 7, 7), (1, 1, 8, 8, 8, 8)):
+        x, z = det_input("x", (B, C, hx, wx), 8, -1, 1), det_input("z", (B, C, hz, wz), 8, -1, 1)
+        xg, zg = G(x).requires_grad_(), G(z).requires_grad_()
+        out = ops.xcorr_depthwise(xg, zg)
+        up = det_input("up", tuple(out.shape), 8, -1, 1)
+        (out * G(up)).sum().backward()
+        xc, zc = T(x).double().requires_grad_(), T(z).double().requires_grad_()
+        oc = torch.nn.functional.conv2d(xc.view(1, B * C, hx, wx), zc.view(B * C, 1, hz, wz), groups=B * C)
+        (oc.view(B, C, *oc.shape[2:]) * T(up).double()).sum().backward()
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(zg.grad.cpu().numpy(), zc.grad.numpy(), rtol=1e-4, atol=1e-4)
