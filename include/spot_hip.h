@@ -209,12 +209,12 @@ int spot_mha_dropout_mask(unsigned char* mask, int B, int nhead, int Lq, int Lk,
  * x,y [rows,C]; mean,rstd [rows] (NULL to skip).  C multiple of 4, <= 1024. */
 int spot_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                            float* rstd, long rows, int C, float eps, hipStream_t stream);
-/* dx, dgamma, dbeta (the latter two overwritten; either may be NULL).  ws: workspace of
+/* dx, dgamma, dbeta (the latter two overwritten, or added to when accumulate != 0; either may be NULL).  ws: workspace of
  * spot_layernorm_bwd_ws_floats(rows, C) floats holding per-workgroup partial sums. */
 long spot_layernorm_bwd_ws_floats(long rows, int C);
 int spot_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd,
                            const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws, long rows,
-                           int C, hipStream_t stream);
+                           int C, int accumulate, hipStream_t stream);
 
 /* Gradients of the two calls above.  d_out [planes, hx-hz+1, wx-wz+1]; dx / dkernel may be NULL to skip. */
 int spot_xcorr_depthwise_bwd_f32(const float* x, const float* kernel, const float* d_out, float* dx,

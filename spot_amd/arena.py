@@ -36,16 +36,27 @@ class ParamArena:
             self.flat_i64[j] = t.data
             t.data = self.flat_i64[j]
         self.grad_flat = None
+        self._ready_listeners = []
         if with_grads:
             self.attach_grads()
 
     def attach_grads(self):
-        """Give every trainable parameter a .grad that is a view into one flat buffer."""
+        """Give every trainable parameter a .grad that is a view into one flat buffer, and mark it as a
+        gradient sink: kernels may add into .grad directly (see ops._sink) and report completion here."""
         self.grad_flat = torch.zeros_like(self.flat)
         for (k, t), o in zip(self.f32, self.offsets):
             if isinstance(t, torch.nn.Parameter) and t.requires_grad:
                 t.grad = self.grad_flat[o:o + t.numel()].view(t.shape)
+                t._spot_grad_sink = self
         return self.grad_flat
+
+    def add_ready_listener(self, fn):
+        self._ready_listeners.append(fn)
+
+    def grad_ready(self, p):
+        """A kernel finished enqueueing p's gradient into p.grad (the autograd hook does not fire for it)."""
+        for fn in self._ready_listeners:
+            fn(p)
 
     def zero_grad(self):
         if self.grad_flat is not None:

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 
 // dgamma|dbeta [2C] = sum over the nblk partial rows; 64 columns per workgroup, 4 waves split the rows
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ partial, int nblk, int C2,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        int accumulate) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
     if (wave == 0 && col < C2) {
         const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
         const int C = C2 >> 1;
-        if (col < C) { if (dgamma) dgamma[col] = t; }
-        else if (dbeta) dbeta[col - C] = t;
+        if (col < C) { if (dgamma) dgamma[col] = accumulate ? dgamma[col] + t : t; }
+        else if (dbeta) dbeta[col - C] = accumulate ? dbeta[col - C] + t : t;
     }
 }
 
@@ -194,10 +195,11 @@ extern "C" long spot_layernorm_bwd_ws_floats(long rows, int C) { return (long)ln
 
 extern "C" int spot_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd,
                                       const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws,
-                                      long rows, int C, hipStream_t stream) {
+                                      long rows, int C, int accumulate, hipStream_t stream) {
     SPOT_CHECK_ARG(rows >= 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXV, "layernorm_bwd: C=%d must be a multiple of 4, <= %d",
                    C, 256 * MAXV);
     if (rows == 0) {
+        if (accumulate) return SPOT_OK;
         if (dgamma) (void)hipMemsetAsync(dgamma, 0, C * sizeof(float), stream);
         if (dbeta) (void)hipMemsetAsync(dbeta, 0, C * sizeof(float), stream);
         return SPOT_OK;
@@ -211,7 +213,7 @@ extern "C" int spot_layernorm_bwd_f32(const float* dy, const float* x, const flo
     ln_bwd_kernel<<<grid, 256, 0, stream>>>(dy, x, mean, rstd, gamma, dx, want ? ws : nullptr, rows, C);
     SPOT_CHECK_LAUNCH("layernorm_bwd");
     if (want) {
-        ln_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, stream>>>(ws, grid, 2 * C, dgamma, dbeta);
+        ln_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, stream>>>(ws, grid, 2 * C, dgamma, dbeta, accumulate);
         SPOT_CHECK_LAUNCH("layernorm_bwd(reduce)");
     }
     return SPOT_OK;

@@ -78,6 +78,7 @@ class GradBucketReducer:
         if self.world > 1:
             for k, t, o in params:
                 t.register_post_accumulate_grad_hook(self._hook)
+            arena.add_ready_listener(self._hook)     # gradients written into .grad by the kernels themselves
 
     def arm(self):
         """Call before backward of each step."""

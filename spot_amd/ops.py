@@ -285,6 +285,29 @@ def groupdw(zs, xs, weight):
 
 
 # ---------------------------------------------------------------------------
+# gradient sinks
+# ---------------------------------------------------------------------------
+# A parameter whose .grad is a preallocated, zero-initialised view of a flat gradient buffer
+# (arena.ParamArena.attach_grads marks it with ``_spot_grad_sink``) receives its gradient
+# inside the producing kernel: the split-K GEMM / column-sum / LayerNorm reduction add
+# straight into .grad and the autograd function returns None for it.  That removes one
+# zero-fill and one add kernel per parameter per step.  The sink is told when a parameter's
+# gradient is complete so that bucketed all-reduce can start while backward continues.
+def _sink(p):
+    if p is None or getattr(p, "_spot_grad_sink", None) is None:
+        return None
+    return p.grad
+
+
+def _sink_done(*params):
+    for p in params:
+        if p is not None:
+            s = getattr(p, "_spot_grad_sink", None)
+            if s is not None and p.grad is not None:
+                s.grad_ready(p)
+
+
+# ---------------------------------------------------------------------------
 # dense contractions
 # ---------------------------------------------------------------------------
 def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None, ldc=None, batch=1,
@@ -396,18 +419,30 @@ class LinearFn(torch.autograd.Function):
         y = linear_fwd(x2, W, b, relu=relu)
         ctx.relu = relu
         ctx.save_for_backward(x2, W, y if relu else None)
-        ctx.has_bias = b is not None
+        ctx.params = (W, b)
         return y.view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, W, y = ctx.saved_tensors
+        pW, pb = ctx.params
         dy2 = _view2d(dy.contiguous())
         if ctx.relu:
             dy2 = torch.where(y > 0, dy2, torch.zeros((), device=dy2.device))
         dx = linear_dgrad(dy2, W) if ctx.needs_input_grad[0] else None
-        dW = linear_wgrad(dy2, x2) if ctx.needs_input_grad[1] else None
-        db = colsum(dy2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dW = db = None
+        if ctx.needs_input_grad[1]:
+            gW = _sink(pW)
+            dW = linear_wgrad(dy2, x2, out=gW, accumulate=gW is not None)
+            if gW is not None:
+                dW = None
+                _sink_done(pW)
+        if pb is not None and ctx.needs_input_grad[2]:
+            gb = _sink(pb)
+            db = colsum(dy2, out=gb)
+            if gb is not None:
+                db = None
+                _sink_done(pb)
         return (dx.view(*dy.shape[:-1], W.shape[1]) if dx is not None else None), dW, db, None
 
 
@@ -428,6 +463,7 @@ class FFNFn(torch.autograd.Function):
         z = linear_fwd(h, W2, b2, residual=x2, drop_p=p, drop_seed=s2)
         ctx.save_for_backward(x2, h, W1, W2)
         ctx.drop = (p, s2)
+        ctx.params = (W1, b1, W2, b2)
         return z.view_as(x)
 
     @staticmethod
@@ -438,12 +474,14 @@ class FFNFn(torch.autograd.Function):
         dzd = dropout_apply(dz2, p, s2)                      # gradient behind the output dropout
         # h > 0 <=> relu passed and the hidden mask kept: one epilogue test, scaled by 1/(1-p)
         dh = linear_dgrad(dzd, W2, mask=h, alpha=1.0 / (1.0 - p))
-        dW2 = linear_wgrad(dzd, h)
-        db2 = colsum(dzd)
         dx = linear_dgrad(dh, W1, residual=dz2)              # FFN path + residual path in one epilogue
-        dW1 = linear_wgrad(dh, x2)
-        db1 = colsum(dh)
-        return dx.view_as(dz), dW1, db1, dW2, db2, None
+        grads = []
+        for prm, dyv, xv in zip(ctx.params, (dh, dh, dzd, dzd), (x2, None, h, None)):
+            g = _sink(prm)
+            r = linear_wgrad(dyv, xv, out=g, accumulate=g is not None) if xv is not None else colsum(dyv, out=g)
+            grads.append(None if g is not None else r)
+        _sink_done(*ctx.params)
+        return (dx.view_as(dz), *grads, None)
 
 
 # ---------------------------------------------------------------------------
@@ -460,6 +498,7 @@ class LayerNormFn(torch.autograd.Function):
         lib.call("spot_layernorm_fwd_f32", _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, Cn,
                  float(eps), _st())
         ctx.save_for_backward(x2, mean, rstd, gamma)
+        ctx.params = (gamma, beta)
         return y.view_as(x)
 
     @staticmethod
@@ -468,11 +507,17 @@ class LayerNormFn(torch.autograd.Function):
         dy2 = _view2d(dy.contiguous())
         rows, Cn = x2.shape
         dx = torch.empty_like(x2)
-        dg = torch.empty_like(gamma)
-        db = torch.empty_like(gamma)
+        pg, pb = ctx.params
+        sg, sb = _sink(pg), _sink(pb)
+        direct = sg is not None and sb is not None
+        dg = sg if direct else torch.empty_like(gamma)
+        db = sb if direct else torch.empty_like(gamma)
         ws = torch.empty((lib.load().spot_layernorm_bwd_ws_floats(rows, Cn),), dtype=torch.float32, device=dy.device)
         lib.call("spot_layernorm_bwd_f32", _p(dy2), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dg), _p(db),
-                 _p(ws), rows, Cn, _st())
+                 _p(ws), rows, Cn, int(direct), _st())
+        if direct:
+            _sink_done(pg, pb)
+            return dx.view_as(dy), None, None, None
         return dx.view_as(dy), dg, db, None
 
 
@@ -559,6 +604,7 @@ class MHAFn(torch.autograd.Function):
             ctx.save_for_backward(xq2, xkv2, pos_q, pos_k, in_w, out_w, qkv, kv, attn, lse, kpm)
             ctx.dims = (B, Lq, Lk, Cn, nhead, dh, self_attn, bool(add_residual))
             ctx.drop = (p_attn, sa, p_out, so)
+            ctx.params = (in_w, in_b, out_w, out_b)
         return z.view(B, Lq, Cn)
 
     @staticmethod
@@ -570,12 +616,14 @@ class MHAFn(torch.autograd.Function):
         dz2 = _view2d(dz.contiguous())
         dzd = dropout_apply(dz2, p_out, so)                  # gradient behind the output dropout
         dattn = linear_dgrad(dzd, out_w)
-        d_out_w = linear_wgrad(dzd, attn)
-        d_out_b = colsum(dzd)
+        p_in_w, p_in_b, p_out_w, p_out_b = ctx.params
+        sinks = [_sink(t) for t in ctx.params]
+        d_out_w = linear_wgrad(dzd, attn, out=sinks[2], accumulate=sinks[2] is not None)
+        d_out_b = colsum(dzd, out=sinks[3])
         delta = torch.empty((B, nhead, Lq), dtype=torch.float32, device=dev)
         scale = 1.0 / math.sqrt(dh)
-        d_in_w = torch.zeros_like(in_w)
-        d_in_b = torch.zeros((3 * Cn,), dtype=torch.float32, device=dev)
+        d_in_w = sinks[0] if sinks[0] is not None else torch.zeros_like(in_w)
+        d_in_b = sinks[1] if sinks[1] is not None else torch.zeros((3 * Cn,), dtype=torch.float32, device=dev)
         if self_attn:
             dqkv = torch.empty_like(qkv)
             lib.call("spot_mha_bwd_f32", _p(qkv), 3 * Cn, _p(qkv[:, Cn:]), 3 * Cn, _p(qkv[:, 2 * Cn:]), 3 * Cn,
@@ -608,12 +656,11 @@ class MHAFn(torch.autograd.Function):
             dk_sum = dkv[:, :Cn].reshape(-1, Rk, Cn).sum(0) if Rk != dkv.shape[0] else dkv[:, :Cn]
             linear_wgrad(dq_sum.contiguous(), pos_q, out=d_in_w[:Cn], accumulate=True)
             linear_wgrad(dk_sum.contiguous(), pos_k, out=d_in_w[Cn:2 * Cn], accumulate=True)
-        if self_attn:
-            # xq and xkv are the same tensor: hand the whole gradient to xq
-            return (dxq.view(B, Lq, Cn), None, None, None, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None, None,
-                    None, None)
-        return (dxq.view(B, Lq, Cn), dxkv.view(B, Lk, Cn), None, None, d_in_w, d_in_b, d_out_w, d_out_b, None,
-                None, None, None, None, None)
+        _sink_done(*ctx.params)
+        pg = [None if sk is not None else g for sk, g in zip(sinks, (d_in_w, d_in_b, d_out_w, d_out_b))]
+        # self-attention: xq and xkv are the same tensor, the whole gradient goes to xq
+        return (dxq.view(B, Lq, Cn), None if self_attn else dxkv.view(B, Lk, Cn), None, None, *pg, None, None, None,
+                None, None, None)
 
 
 def mha_block(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn,

@@ -27,6 +27,14 @@ class NecessaryPreprocess(nn.Module):
         self.brightness_jitter = b_j
         self.mean = list(mean)
         self.std = list(std)
+        self._dev_stats = {}
+
+    def _stats(self, device):
+        # cached per device: building them per call is a blocking pageable host-to-device copy
+        if device not in self._dev_stats:
+            self._dev_stats[device] = (torch.as_tensor(self.mean, dtype=torch.float32, device=device),
+                                       torch.as_tensor(self.std, dtype=torch.float32, device=device))
+        return self._dev_stats[device]
 
     def forward(self, data, tag="template"):
         images, avg = data[tag + "_images"], data[tag + "_avg"]
@@ -40,8 +48,7 @@ class NecessaryPreprocess(nn.Module):
             f = None
         im = ops.preprocess_u8(images.contiguous(), f, self.mean, self.std)
         fa = (f if f is not None else torch.full([B], 1.0 / 255.0, device=images.device))[:, None]
-        m = torch.as_tensor(self.mean, device=avg.device)
-        s = torch.as_tensor(self.std, device=avg.device)
+        m, s = self._stats(avg.device)
         avg_out = ((avg.float() * fa).clamp(0.0, 1.0) - m) / s
         return im, avg_out
 
@@ -59,6 +66,7 @@ class InputProjFn(torch.autograd.Function):
         ops.gemm(feat, w2, out, HW, Cout, Cin, transA=True, lda=HW, ldb=Cin, ldc=Cout, batch=B,
                  strideA=Cin * HW, strideC=HW * Cout, bias=bias)
         ctx.save_for_backward(feat, weight)
+        ctx.params = (weight, bias)
         return out
 
     @staticmethod
@@ -73,13 +81,18 @@ class InputProjFn(torch.autograd.Function):
             dfeat = torch.empty_like(feat)
             ops.gemm(w2, dtok, dfeat, Cin, HW, Cout, transA=True, lda=Cin, ldb=Cout, ldc=HW, batch=B,
                      strideB=HW * Cout, strideC=Cin * HW)
+        pw, pb = ctx.params
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w2)
+            sk = ops._sink(pw)
+            dw = sk.view(Cout, Cin) if sk is not None else torch.zeros_like(w2)
             ops.gemm(dtok, feat, dw, Cout, Cin, B * HW, transA=True, lda=Cout, ldb=HW, ldc=Cin, kseg=HW,
                      segA=HW * Cout, segB=Cin * HW, splitk=max(1, min(B * HW // 256, 32)), accumulate=True)
-            dw = dw.view_as(weight)
+            dw = None if sk is not None else dw.view_as(weight)
         if ctx.needs_input_grad[2]:
-            db = ops.colsum(dtok.view(-1, Cout))
+            sk = ops._sink(pb)
+            db = ops.colsum(dtok.view(-1, Cout), out=sk)
+            db = None if sk is not None else db
+        ops._sink_done(pw, pb)
         return dfeat, dw, db
 
 
