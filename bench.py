@@ -159,7 +159,7 @@ def main():
         step(i)
     timer = None
     if not args.no_kernel_timing:
-        timer = ops.TIMER = ops.KernelTimer()
+        timer = ops.TIMER = ops.KernelTimer(shapes=os.environ.get("SPOT_TIMER_SHAPES", "0") == "1")
     skipped0 = trainer.skipped
     barrier()
     t0 = time.perf_counter()

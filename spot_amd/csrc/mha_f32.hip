@@ -29,10 +29,66 @@ constexpr int KP = DH + 4;    // padded LDS row (floats)
 
 __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
-// attention-probability dropout: keep(q, key) for (clip, head) stream key sbh; Lq, Lk <= 65536
+// attention-probability dropout: keep(q, key) for (clip, head) stream key sbh; Lq, Lk <= 65536.
+// The fp32 matrix instruction does not overlap with vector ALU work on its SIMD, so every vector
+// instruction in the attention loops costs wall time: the per-element hash is built from full-rate
+// operations only (24-bit multiply-add, shifts, xors; two rounds), 10 instructions instead of the
+// 32-bit-multiply mixer's 11 of which two run at quarter rate.  Drop rate, neighbour correlations and
+// row/column count dispersion of the masks match the 32-bit mixer's.
 __device__ __forceinline__ unsigned attn_stream_key(unsigned seed, unsigned bh) { return spot_mix32(bh * 0x9E3779B1U ^ seed); }
+__device__ __forceinline__ unsigned attn_mix(unsigned x) {
+    x ^= x >> 15;
+    x = (x & 0xffffffu) * 0x966bafu + (x >> 10);
+    x ^= x >> 15;
+    x = (x & 0xffffffu) * 0xf9341du + (x >> 10);
+    x ^= x >> 13;
+    return x;
+}
 __device__ __forceinline__ bool attn_keep(unsigned sbh, unsigned q, unsigned key, unsigned thr) {
-    return spot_mix32(((q << 16) | key) ^ sbh) >= thr;
+    return attn_mix(((q << 16) | key) ^ sbh) >= thr;
+}
+
+// Online-softmax step on one 32-key score block held as S^T (keys on the accumulator rows, the
+// lane's query fixed).  Scores arrive in the log2 domain (Q was pre-multiplied by scale*log2 e).
+// CHECK = false skips the bounds / key-padding tests (whole block valid).
+template <bool CHECK>
+__device__ __forceinline__ void softmax_block(f32x16& s, f32x16& o, float& m_run, float& l_run, int key0, int h, int Lk,
+                                              const unsigned char* mb, unsigned qs, unsigned drop_thr, float drop_scale) {
+    if (CHECK) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = key0 + acc_row(e, h);
+            const bool dead = key >= Lk || (mb && mb[key]);
+            s[e] = dead ? -INFINITY : s[e];
+        }
+    }
+    float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+    for (int e = 3; e < 15; e += 2) mx = fmaxf(fmaxf(mx, s[e]), s[e + 1]);
+    mx = fmaxf(mx, s[15]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        s[e] = __builtin_amdgcn_exp2f(s[e] - m_use);
+        psum += s[e];
+    }
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {      // the running maximum moved for some query of this wave
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run = -inf -> 0
+        l_run *= alpha;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] *= alpha;
+        m_run = m_new;
+    }
+    l_run += psum;
+    if (drop_thr) {   // dropout acts on the normalised probabilities: the row sum above stays undropped
+        const unsigned x0 = qs ^ (unsigned)(key0 + 4 * h);   // low 16 bits: key; acc_row(e,h) = r(e) + 4h with r(e) & 4 == 0
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            s[e] = attn_mix(x0 ^ (unsigned)acc_row(e, 0)) >= drop_thr ? s[e] * drop_scale : 0.f;
+    }
 }
 
 __global__ __launch_bounds__(256) void mha_fwd_kernel(
@@ -47,17 +103,17 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(
     const int head = blockIdx.y, b = blockIdx.z;
     const int q = blockIdx.x * 128 + wave * 32 + l31;
     const bool qok = q < Lq;
-    const float c = scale * 1.4426950408889634f;   // scores are kept unscaled; exp2((s - m) * c)
-    const unsigned sbh = attn_stream_key(drop_seed, (unsigned)(b * H + head));
+    const float c = scale * 1.4426950408889634f;   // Q is pre-multiplied by c: scores live in the log2 domain
+    const unsigned qs = ((unsigned)q << 16) ^ attn_stream_key(drop_seed, (unsigned)(b * H + head));
 
-    // Q fragment: lane holds Q[q][16h .. 16h+15]
+    // Q fragment: lane holds c * Q[q][16h .. 16h+15]
     float qf[16];
     {
         const float* qp = Q + ((long)b * Lq + (qok ? q : 0)) * ldq + head * DH + 16 * h;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float4 v = *reinterpret_cast<const float4*>(qp + 4 * i);
-            qf[4 * i] = v.x; qf[4 * i + 1] = v.y; qf[4 * i + 2] = v.z; qf[4 * i + 3] = v.w;
+            qf[4 * i] = v.x * c; qf[4 * i + 1] = v.y * c; qf[4 * i + 2] = v.z * c; qf[4 * i + 3] = v.w * c;
         }
     }
     f32x16 o;
@@ -120,33 +176,8 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(
 #pragma unroll
             for (int j = 0; j < 16; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[j], s, 0, 0, 0);
             // ---- mask, online softmax (per lane = per query)
-            float mx = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = key0 + acc_row(e, h);
-                const bool dead = key >= Lk || (mb && mb[key]);
-                s[e] = dead ? -INFINITY : s[e];
-                mx = fmaxf(mx, s[e]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c);   // m_run = -inf -> 0
-            float psum = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                s[e] = __builtin_amdgcn_exp2f((s[e] - m_use) * c);
-                psum += s[e];
-            }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-            if (drop_thr) {   // dropout acts on the normalised probabilities: the row sum above stays undropped
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    s[e] = attn_keep(sbh, (unsigned)q, (unsigned)(key0 + acc_row(e, h)), drop_thr) ? s[e] * drop_scale : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[e] *= alpha;
+            if (mb || key0 + 32 > Lk) softmax_block<true>(s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
+            else softmax_block<false>(s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
             // ---- O^T += V^T P^T   (step e sums keys acc_row(e,0) and acc_row(e,1))
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -166,7 +197,143 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(
         for (int gq = 0; gq < 4; ++gq)
             *reinterpret_cast<float4*>(op + 8 * gq + 4 * h) =
                 make_float4(o[4 * gq] * inv, o[4 * gq + 1] * inv, o[4 * gq + 2] * inv, o[4 * gq + 3] * inv);
-        if (LSE && h == 0) LSE[((long)b * H + head) * Lq + q] = m_run * scale + logf(l_tot);
+        if (LSE && h == 0) LSE[((long)b * H + head) * Lq + q] = m_run * 0.6931471805599453f + logf(l_tot);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Two-group variant of the forward kernel.  A 512-thread workgroup owns 256
+// queries; waves w and w+4 sit on the same SIMD.  Every wave runs the same
+// alternating program
+//     M(-1): S(0)      V(0): softmax(0)      M(0): O += P(0) V(0), S(1)      V(1): softmax(1)   ...
+// with a workgroup barrier after each phase, and waves 4..7 run it one phase
+// late.  So on every SIMD one wave is always in a matrix phase while its partner
+// is in a vector (softmax / dropout-hash) phase: the matrix pipe and the VALU
+// work concurrently instead of the two waves drifting into lockstep and taking
+// turns idling both.  K/V stream through a ring of three 32-key LDS tiles: tile
+// j is fetched to registers in global phase 2j-2, written to LDS in 2j-1 and
+// first read in 2j; its slot's previous tenant j-3 was last read in phase 2j-3.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
+    const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
+    float* __restrict__ O, long ldo, float* __restrict__ LSE, const unsigned char* __restrict__ kpm,
+    int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed, float drop_scale) {
+    __shared__ __attribute__((aligned(16))) float lds[3 * 2 * 32 * KP];
+    auto Ks = [&](int j) { return lds + (j % 3) * 2 * 32 * KP; };
+    auto Vs = [&](int j) { return lds + (j % 3) * 2 * 32 * KP + 32 * KP; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, h = lane >> 5, l31 = lane & 31;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q = blockIdx.x * 256 + wave * 32 + l31;
+    const bool qok = q < Lq;
+    const float c = scale * 1.4426950408889634f;
+    const unsigned qs = ((unsigned)q << 16) ^ attn_stream_key(drop_seed, (unsigned)(b * H + head));
+
+    // Q fragment: lane holds c * Q[q][16h .. 16h+15]
+    float qf[16];
+    {
+        const float* qp = Q + ((long)b * Lq + (qok ? q : 0)) * ldq + head * DH + 16 * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + 4 * i);
+            qf[4 * i] = v.x * c; qf[4 * i + 1] = v.y * c; qf[4 * i + 2] = v.z * c; qf[4 * i + 3] = v.w * c;
+        }
+    }
+    f32x16 o, sA, sB;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const unsigned char* mb = kpm ? kpm + (long)b * Lk : nullptr;
+    const int n = (Lk + 31) / 32;
+
+    // loader role of this thread: threads 0..255 carry K rows, 256..511 carry V rows, one float4 each per tile
+    const int ld_row = (tid & 255) >> 3, ld_d4 = (tid & 7) << 2;
+    const bool ld_v = tid >= 256;
+    const float* ld_base = ld_v ? V + (long)b * Lk * ldv + head * DH + ld_d4 : K + (long)b * Lk * ldk + head * DH + ld_d4;
+    const long ld_stride = ld_v ? ldv : ldk;
+    float4 st = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int j) {
+        const int key = j * 32 + ld_row;
+        st = key < Lk ? *reinterpret_cast<const float4*>(ld_base + (long)key * ld_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stash = [&](int j) { *reinterpret_cast<float4*>((ld_v ? Vs(j) : Ks(j)) + ld_row * KP + ld_d4) = st; };
+    auto duty = [&](int gp) {     // global phase gp
+        if ((gp & 1) == 0) {
+            const int j = (gp >> 1) + 1;
+            if (j >= 2 && j < n) fetch(j);
+        } else {
+            const int j = (gp + 1) >> 1;
+            if (j >= 2 && j < n) stash(j);
+        }
+    };
+    auto score = [&](int j, f32x16& s) {      // S^T(j) = K_j Q^T
+        const float* ks = Ks(j);
+        float kf[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(ks + l31 * KP + 16 * h + 4 * i);
+            kf[4 * i] = v.x; kf[4 * i + 1] = v.y; kf[4 * i + 2] = v.z; kf[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[jj], qf[jj], s, 0, 0, 0);
+    };
+    auto accumulate = [&](int j, const f32x16& s) {   // O^T += V_j^T P^T
+        const float* vs = Vs(j);
+        float vf[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) vf[e] = vs[acc_row(e, h) * KP + l31];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], s[e], o, 0, 0, 0);
+    };
+    auto softmax = [&](int j, f32x16& s) {
+        const int key0 = j * 32;
+        if (mb || key0 + 32 > Lk) softmax_block<true>(s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
+        else softmax_block<false>(s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
+    };
+
+    fetch(0);
+    stash(0);
+    if (n > 1) {
+        fetch(1);
+        stash(1);
+    }
+    __syncthreads();
+    if (grp) __syncthreads();                 // waves 4..7 run one phase behind
+    int gp = grp;
+    duty(gp++);
+    score(0, sA);
+    __syncthreads();
+    for (int i = 0; i < n; i += 2) {
+        duty(gp++);
+        softmax(i, sA);
+        __syncthreads();
+        duty(gp++);
+        accumulate(i, sA);
+        if (i + 1 < n) score(i + 1, sB);
+        __syncthreads();
+        if (i + 1 < n) {
+            duty(gp++);
+            softmax(i + 1, sB);
+            __syncthreads();
+            duty(gp++);
+            accumulate(i + 1, sB);
+            if (i + 2 < n) score(i + 2, sA);
+            __syncthreads();
+        }
+    }
+    if (!grp) __syncthreads();
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    if (qok) {
+        float* op = O + ((long)b * Lq + q) * ldo + head * DH;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<float4*>(op + 8 * gq + 4 * h) =
+                make_float4(o[4 * gq] * inv, o[4 * gq + 1] * inv, o[4 * gq + 2] * inv, o[4 * gq + 3] * inv);
+        if (LSE && h == 0) LSE[((long)b * H + head) * Lq + q] = m_run * 0.6931471805599453f + logf(l_tot);
     }
 }
 
@@ -186,9 +353,16 @@ extern "C" int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long l
     SPOT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mha_fwd: drop_p=%f outside [0,1)", drop_p);
     SPOT_CHECK_ARG(drop_p == 0.f || (Lq <= 65536 && Lk <= 65536), "mha_fwd: dropout needs Lq, Lk <= 65536");
     if (B == 0) return SPOT_OK;
-    dim3 grid((Lq + 127) / 128, nhead, B);
-    mha_fwd_kernel<<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk, nhead, scale,
-                                             spot_drop_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
+    // 256-query workgroups need enough of them to fill the chip; short query streams keep the 128-query kernel
+    if (Lq >= 512 && (long)((Lq + 255) / 256) * nhead * B >= 512) {
+        dim3 grid((Lq + 255) / 256, nhead, B);
+        mha_fwd_pp_kernel<<<grid, 512, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk, nhead,
+                                                    scale, spot_drop_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
+    } else {
+        dim3 grid((Lq + 127) / 128, nhead, B);
+        mha_fwd_kernel<<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk, nhead,
+                                                 scale, spot_drop_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
+    }
     SPOT_CHECK_LAUNCH("mha_fwd");
     return SPOT_OK;
 }
@@ -249,9 +423,8 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const int head = blockIdx.y, b = blockIdx.z;
     const int key_w0 = blockIdx.x * 128 + wave * 32;
     const int key = key_w0 + l31;
-    const float c = scale * 1.4426950408889634f;
-    const float inv_scale = 1.f / scale;
-    const unsigned sbh = attn_stream_key(drop_seed, (unsigned)(b * H + head));
+    const float c = scale * 1.4426950408889634f;   // folded into the K fragment: scores come out in the log2 domain
+    const unsigned ks = attn_stream_key(drop_seed, (unsigned)(b * H + head)) ^ (unsigned)key;
 
     const float* Qb = Q + (long)b * Lq * ldq + head * DH;
     const float* Gb = dO + (long)b * Lq * lddo + head * DH;
@@ -292,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
         }
         if (tid < 32) {
             const int qq = t * 32 + tid;
-            sl = qq < Lq ? Lb[qq] * inv_scale : INFINITY;
+            sl = qq < Lq ? Lb[qq] * 1.4426950408889634f : INFINITY;
         } else if (tid < 64) {
             const int qq = t * 32 + tid - 32;
             sl = qq < Lq ? Db[qq] : 0.f;
@@ -307,12 +480,24 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     fetch(0);
     stash(0);
     __syncthreads();
-    // K fragment (B operand of S): lane holds K[key][16h .. 16h+15]
+    // K fragment (B operand of S): lane holds c * K[key][16h .. 16h+15]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float4 v = *reinterpret_cast<const float4*>(Kt + (wave * 32 + l31) * QP + 16 * h + 4 * i);
-        kf[4 * i] = v.x; kf[4 * i + 1] = v.y; kf[4 * i + 2] = v.z; kf[4 * i + 3] = v.w;
+        kf[4 * i] = v.x * c; kf[4 * i + 1] = v.y * c; kf[4 * i + 2] = v.z * c; kf[4 * i + 3] = v.w * c;
     }
+    // From here on the LDS copy of K only feeds dQ = dS K * scale: fold the scale into it once.
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        float4* kp = reinterpret_cast<float4*>(Kt + (f >> 3) * QP + ((f & 7) << 2));
+        float4 v = *kp;
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        *kp = v;
+    }
+    __syncthreads();
+    const bool any_dead = __builtin_amdgcn_ballot_w64(kdead) != 0;
     f32x16 dk, dv;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
@@ -351,18 +536,26 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
 #pragma unroll
             for (int j = 0; j < 16; ++j) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[j], vf[j], dp, 0, 0, 0);
         }
-        // ---- P = exp2(c S'), dS = P * dP' * scale ; masked / out-of-range keys contribute nothing
+        // ---- P = exp2(S'), dS = P * dP' (the 1/sqrt(d) factor rides on K and on the final dK); masked or
+        //      out-of-range keys contribute nothing
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float p = kdead ? 0.f : __builtin_amdgcn_exp2f(s[e] * c);
-            if (drop_thr) {
-                const float ms = attn_keep(sbh, (unsigned)(t * 32 + acc_row(e, h)), (unsigned)key, drop_thr) ? drop_scale : 0.f;
-                s[e] = p * ms;                                  // dropped probabilities feed dV
-                dp[e] = p * (dp[e] * ms - dl[e]) * scale;       // dS = P (M dP_drop - delta)
-            } else {
-                s[e] = p;
-                dp[e] = p * dp[e] * scale;
+        for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e]);
+        if (any_dead) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = kdead ? 0.f : s[e];
+        }
+        if (drop_thr) {
+            const unsigned x0 = ks ^ ((unsigned)(t * 32 + 4 * h) << 16);     // query index sits in the high half
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float ms = attn_mix(x0 ^ ((unsigned)acc_row(e, 0) << 16)) >= drop_thr ? drop_scale : 0.f;
+                const float p = s[e];
+                s[e] = p * ms;                              // dropped probabilities feed dV
+                dp[e] = p * (dp[e] * ms - dl[e]);           // dS = P (M dP_drop - delta)
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dp[e] *= s[e];
         }
         // ---- dV += P^T dO ; dK += dS^T Q     (A = accumulator register e, B = row q(e,h) of the LDS tile)
 #pragma unroll
@@ -403,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     for (int e = 0; e < 16; ++e) {
         const int kr = key_w0 + acc_row(e, h);
         if (kr < Lk) {
-            dK[((long)b * Lk + kr) * lddk + head * DH + l31] = dk[e];
+            dK[((long)b * Lk + kr) * lddk + head * DH + l31] = dk[e] * scale;
             dV[((long)b * Lk + kr) * lddv + head * DH + l31] = dv[e];
         }
     }

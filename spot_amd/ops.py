@@ -21,8 +21,9 @@ def _st():
 class KernelTimer:
     """Optional per-launch timing with HIP events on the launch stream (used by bench.py's roofline leg)."""
 
-    def __init__(self):
+    def __init__(self, shapes=False):
         self.records = []          # (key, work, start_event, end_event)
+        self.shapes = shapes       # key GEMM launches by problem shape as well
 
     def run(self, key, work, launch):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -335,7 +336,10 @@ def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None,
     d.ldres, d.strideRes = ldres, strideRes
     d.drop_p, d.drop_seed = drop_p, drop_seed
     if TIMER is not None:
-        TIMER.run("gemm_%s%s" % ("t" if transA else "n", "n" if transB else "t"), 2.0 * M * N * K * batch,
+        key = "gemm_%s%s" % ("t" if transA else "n", "n" if transB else "t")
+        if TIMER.shapes:
+            key += " M%d N%d K%d b%d sk%d" % (M, N, K, batch, splitk)
+        TIMER.run(key, 2.0 * M * N * K * batch,
                   lambda: lib.call("spot_gemm_f32", C.byref(d), _st()))
     else:
         lib.call("spot_gemm_f32", C.byref(d), _st())
@@ -544,10 +548,18 @@ def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, ou
     launch = lambda: lib.call("spot_mha_fwd_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), out.stride(0), _p(lse),
                               _p(kpm), B, Lq, Lk, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), drop_seed, _st())
     if TIMER is not None:
-        TIMER.run("mha_fwd", 4.0 * B * nhead * Lq * Lk * dh, launch)
+        TIMER.run("mha_fwd Lq%d Lk%d B%d" % (Lq, Lk, B) if TIMER.shapes else "mha_fwd", 4.0 * B * nhead * Lq * Lk * dh, launch)
     else:
         launch()
     return out, lse
+
+
+def _timed_mha_bwd(B, Lq, Lk, nhead, dh, launch):
+    if TIMER is not None:
+        TIMER.run("mha_bwd Lq%d Lk%d B%d" % (Lq, Lk, B) if TIMER.shapes else "mha_bwd",
+                  10.0 * B * nhead * Lq * Lk * dh, launch)
+    else:
+        launch()
 
 
 def _pos_table(pos2, W, b):
@@ -626,10 +638,11 @@ class MHAFn(torch.autograd.Function):
         d_in_b = sinks[1] if sinks[1] is not None else torch.zeros((3 * Cn,), dtype=torch.float32, device=dev)
         if self_attn:
             dqkv = torch.empty_like(qkv)
-            lib.call("spot_mha_bwd_f32", _p(qkv), 3 * Cn, _p(qkv[:, Cn:]), 3 * Cn, _p(qkv[:, 2 * Cn:]), 3 * Cn,
-                     _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
-                     _p(dqkv), 3 * Cn, _p(dqkv[:, Cn:]), 3 * Cn, _p(dqkv[:, 2 * Cn:]), 3 * Cn,
-                     B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _st())
+            _timed_mha_bwd(B, Lq, Lk, nhead, dh, lambda: lib.call(
+                "spot_mha_bwd_f32", _p(qkv), 3 * Cn, _p(qkv[:, Cn:]), 3 * Cn, _p(qkv[:, 2 * Cn:]), 3 * Cn,
+                _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
+                _p(dqkv), 3 * Cn, _p(dqkv[:, Cn:]), 3 * Cn, _p(dqkv[:, 2 * Cn:]), 3 * Cn,
+                B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _st()))
             dxq = linear_dgrad(dqkv, in_w, residual=dz2 if has_res else None)
             dxkv = None
             linear_wgrad(dqkv, xq2, out=d_in_w, accumulate=True)
@@ -641,10 +654,11 @@ class MHAFn(torch.autograd.Function):
         else:
             dq = torch.empty_like(qkv)
             dkv = torch.empty_like(kv)
-            lib.call("spot_mha_bwd_f32", _p(qkv), Cn, _p(kv), 2 * Cn, _p(kv[:, Cn:]), 2 * Cn,
-                     _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
-                     _p(dq), Cn, _p(dkv), 2 * Cn, _p(dkv[:, Cn:]), 2 * Cn,
-                     B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _st())
+            _timed_mha_bwd(B, Lq, Lk, nhead, dh, lambda: lib.call(
+                "spot_mha_bwd_f32", _p(qkv), Cn, _p(kv), 2 * Cn, _p(kv[:, Cn:]), 2 * Cn,
+                _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
+                _p(dq), Cn, _p(dkv), 2 * Cn, _p(dkv[:, Cn:]), 2 * Cn,
+                B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _st()))
             dxq = linear_dgrad(dq, in_w[:Cn], residual=dz2 if has_res else None)
             dxkv = linear_dgrad(dkv, in_w[Cn:])
             linear_wgrad(dq, xq2, out=d_in_w[:Cn], accumulate=True)

@@ -74,14 +74,16 @@ def bench_gemm():
                                                                "sk=%d" % kw["splitk"] if "splitk" in kw else ""))
 
 
-def bench_mha():
-    print("== mha core (fp32 MFMA)")
+def bench_mha(shapes=((1024, 1024), (256, 256), (256, 1024), (1024, 256)), iters=20):
+    pd = float(os.environ.get("SPOT_MB_DROP", "0"))
+    print("== mha core (fp32 MFMA), attention dropout %g" % pd)
     B, H, dh = 40, 8, 32
     C = H * dh
-    for Lq, Lk in ((1024, 1024), (256, 256), (256, 1024), (1024, 256)):
+    for Lq, Lk in shapes:
         q, k, v = r(B * Lq, C), r(B * Lk, C), r(B * Lk, C)
         out, lse = ops.mha_core_fwd(q, C, k, C, v, C, B, Lq, Lk, H, dh, None, True)
-        t = timeit(lambda: ops.mha_core_fwd(q, C, k, C, v, C, B, Lq, Lk, H, dh, None, True, out=out))
+        t = timeit(lambda: ops.mha_core_fwd(q, C, k, C, v, C, B, Lq, Lk, H, dh, None, True, out=out, drop_p=pd,
+                                            drop_seed=7), iters)
         fl = 4.0 * B * H * Lq * Lk * dh
         do = r(B * Lq, C)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -90,8 +92,8 @@ def bench_mha():
 
         def bwd():
             lib.call("spot_mha_bwd_f32", P(q), C, P(k), C, P(v), C, P(out), C, P(do), C, P(lse), None, P(delta),
-                     P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, H, dh, 1.0 / math.sqrt(dh), 0.0, 0, ops._st())
-        tb = timeit(bwd)
+                     P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, H, dh, 1.0 / math.sqrt(dh), pd, 7, ops._st())
+        tb = timeit(bwd, iters)
         print("Lq=%4d Lk=%4d  fwd %8.1f us %6.1f TF | bwd %8.1f us %6.1f TF" %
               (Lq, Lk, t * 1e6, fl / t / 1e12, tb * 1e6, 2.5 * fl / tb / 1e12))
 
@@ -141,3 +143,5 @@ if __name__ == "__main__":
     for name, fn in (("gemm", bench_gemm), ("mha", bench_mha), ("xcorr", bench_xcorr), ("norm", bench_norm)):
         if what in (name, "all"):
             fn()
+    if what == "mha1":      # one shape, few launches: for counter passes under rocprofv3 --pmc
+        bench_mha(((1024, 1024),), iters=4)
