@@ -48,6 +48,7 @@ def build_job(args, rank):
     # the reference's training configuration: dropout 0.1, brightness jitter 0.2 (spot_transt_003.py:80,85)
     S = Settings(device="cuda", dropout=args.dropout, batch_size_sup=args.sup, batch_size_unsup=args.clips)
     S.aug_settings["jitter"] = 0.2
+    S.attention_dtype = args.attention
     ops_seed = 1000 + rank
     from spot_amd import ops as _ops
     _ops.manual_seed(ops_seed)
@@ -136,6 +137,8 @@ def main():
     ap.add_argument("--clips", type=int, default=32, help="unlabelled clips per GPU per step")
     ap.add_argument("--sup", type=int, default=8, help="labelled pairs per GPU per step")
     ap.add_argument("--dropout", type=float, default=0.1, help="student dropout (reference config: 0.1)")
+    ap.add_argument("--attention", choices=("f32", "bf16"), default="f32",
+                    help="attention-core matrix products: exact fp32 (default, the headline config) or bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -196,12 +199,14 @@ def main():
             "metric": "tracked frames/sec (fwd-bwd pseudo-labelling + train step)",
             "value": round(done * args.clips * world / el, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.attention == "f32" else "f32 (bf16 attention products)", "data": "synthetic",
             "config": {"workload": "cfg2: %d clips x 3 frames per GPU per step; teacher pseudo-label + decode + "
                                    "filter + compaction + student fwd/bwd/AdamW on %d labelled + %d pseudo-labelled "
-                                   "pairs (TransT ResNet-50, 128^2 template / 256^2 search, fp32, student dropout %g, "
+                                   "pairs (TransT ResNet-50, 128^2 template / 256^2 search, fp32%s, student dropout %g, "
                                    "brightness jitter 0.2, teacher in eval mode)"
-                                   % (args.clips, args.sup, args.clips, args.dropout),
+                                   % (args.clips, args.sup, args.clips, "" if args.attention == "f32" else
+                                      " with bf16 attention products", args.dropout),
                        "clips_per_gpu": args.clips, "sup_pairs_per_gpu": args.sup, "skipped_steps": args.steps - done,
                        "parallelism": "dp%d" % world},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,

@@ -199,6 +199,18 @@ int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long ldk, const f
                      const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq,
                      float* dk, long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead,
                      int head_dim, float scale, float drop_p, unsigned drop_seed, hipStream_t stream);
+/* Same contracts as spot_mha_fwd_f32 / spot_mha_bwd_f32, with the five matrix products taken in bf16
+ * (operands rounded to bf16 in registers, fp32 accumulation, fp32 softmax): the "bf16 MFMA attention" training
+ * configuration.  Inputs, outputs and saved statistics stay fp32. */
+int spot_mha_fwd_bf16(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                      float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B, int Lq,
+                      int Lk, int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed,
+                      hipStream_t stream);
+int spot_mha_bwd_bf16(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                      const float* out, long ldo, const float* d_out, long lddo, const float* lse,
+                      const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq, float* dk,
+                      long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead, int head_dim,
+                      float scale, float drop_p, unsigned drop_seed, hipStream_t stream);
 /* The mask the two calls above use, as bytes [B,nhead,Lq,Lk] (1 = kept); for host-side verification. */
 int spot_mha_dropout_mask(unsigned char* mask, int B, int nhead, int Lq, int Lk, float drop_p,
                           unsigned drop_seed, hipStream_t stream);

@@ -1,4 +1,5 @@
-// Fused multi-head attention core, fp32 on the matrix cores, head dim 32.
+// Fused multi-head attention core on the matrix cores, head dim 32: exact fp32 products, or bf16
+// products with fp32 softmax and accumulation (the *_bf16 entry points).
 //
 // Replaces the QK^T -> key-padding mask -> softmax -> (dropout) -> PV middle of
 // nn.MultiheadAttention as the fusion layers call it
@@ -22,6 +23,51 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// One 32x32 (+)= [32 x 32] x [32 x 32] product per call.  A lane's operand fragment is 16 values
+// of its row/column: with the lane-half h owning reduction indices 16h .. 16h+15 on BOTH operands
+// (the MFMA only needs the two operands to agree on which index sits where), the fp32 path issues
+// 16 v_mfma_f32_32x32x2_f32 (step j pairs index j of either half) and the bf16 path converts the
+// same 16 values to two 8-wide bf16 operands and issues 2 v_mfma_f32_32x32x16_bf16; accumulation
+// is fp32 in both.
+template <bool BF16> struct Frag;
+template <> struct Frag<false> {
+    float f[16];
+    __device__ __forceinline__ void set(int i, float x) { f[i] = x; }
+};
+template <> struct Frag<true> {
+    bf16x8 v[2];
+    __device__ __forceinline__ void set(int i, float x) { v[i >> 3][i & 7] = (__bf16)x; }
+};
+__device__ __forceinline__ void mma(const Frag<false>& a, const Frag<false>& b, f32x16& acc) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[j], b.f[j], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(const Frag<true>& a, const Frag<true>& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[0], b.v[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[1], b.v[1], acc, 0, 0, 0);
+}
+// fragment = 16 consecutive floats of an LDS / global row (16-byte aligned), times mul
+template <bool BF16>
+__device__ __forceinline__ void load_frag(Frag<BF16>& fr, const float* p, float mul = 1.f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 4 * i);
+        fr.set(4 * i, v.x * mul); fr.set(4 * i + 1, v.y * mul); fr.set(4 * i + 2, v.z * mul); fr.set(4 * i + 3, v.w * mul);
+    }
+}
+// fragment = the lane's column of a row-major LDS tile at the 16 rows its accumulator registers map to
+template <bool BF16>
+__device__ __forceinline__ void load_frag_rows(Frag<BF16>& fr, const float* tile, int ld, int h, int col) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) fr.set(e, tile[((e & 3) + 8 * (e >> 2) + 4 * h) * ld + col]);
+}
+template <bool BF16>
+__device__ __forceinline__ void acc_frag(Frag<BF16>& fr, const f32x16& a) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) fr.set(e, a[e]);
+}
 
 constexpr int DH = 32;        // head dim
 constexpr int KT = 64;        // keys per LDS tile
@@ -91,7 +137,8 @@ __device__ __forceinline__ void softmax_block(f32x16& s, f32x16& o, float& m_run
     }
 }
 
-__global__ __launch_bounds__(256) void mha_fwd_kernel(
+template <bool BF16>
+__global__ __launch_bounds__(256, 3) void mha_fwd_kernel(
     const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
     float* __restrict__ O, long ldo, float* __restrict__ LSE, const unsigned char* __restrict__ kpm,
     int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed, float drop_scale) {
@@ -107,15 +154,8 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(
     const unsigned qs = ((unsigned)q << 16) ^ attn_stream_key(drop_seed, (unsigned)(b * H + head));
 
     // Q fragment: lane holds c * Q[q][16h .. 16h+15]
-    float qf[16];
-    {
-        const float* qp = Q + ((long)b * Lq + (qok ? q : 0)) * ldq + head * DH + 16 * h;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(qp + 4 * i);
-            qf[4 * i] = v.x * c; qf[4 * i + 1] = v.y * c; qf[4 * i + 2] = v.z * c; qf[4 * i + 3] = v.w * c;
-        }
-    }
+    Frag<BF16> qf;
+    load_frag(qf, Q + ((long)b * Lq + (qok ? q : 0)) * ldq + head * DH + 16 * h, c);
     f32x16 o;
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] = 0.f;
@@ -167,22 +207,20 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(
             f32x16 s;
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e] = 0.f;
-            float kf[16];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 v = *reinterpret_cast<const float4*>(ks + l31 * KP + 16 * h + 4 * i);
-                kf[4 * i] = v.x; kf[4 * i + 1] = v.y; kf[4 * i + 2] = v.z; kf[4 * i + 3] = v.w;
+            {
+                Frag<BF16> kf;
+                load_frag(kf, ks + l31 * KP + 16 * h);
+                mma(kf, qf, s);
             }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[j], s, 0, 0, 0);
             // ---- mask, online softmax (per lane = per query)
             if (mb || key0 + 32 > Lk) softmax_block<true>(s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
             else softmax_block<false>(s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
-            // ---- O^T += V^T P^T   (step e sums keys acc_row(e,0) and acc_row(e,1))
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float vf = vs[acc_row(e, h) * KP + l31];
-                o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[e], o, 0, 0, 0);
+            // ---- O^T += V^T P^T   (reduction slot e of half h is key acc_row(e,h): the S^T accumulator IS the operand)
+            {
+                Frag<BF16> vf, pf;
+                load_frag_rows(vf, vs, KP, h, l31);
+                acc_frag(pf, s);
+                mma(vf, pf, o);
             }
         }
         if (more) stash(cur ^ 1);
@@ -230,15 +268,8 @@ __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
     const unsigned qs = ((unsigned)q << 16) ^ attn_stream_key(drop_seed, (unsigned)(b * H + head));
 
     // Q fragment: lane holds c * Q[q][16h .. 16h+15]
-    float qf[16];
-    {
-        const float* qp = Q + ((long)b * Lq + (qok ? q : 0)) * ldq + head * DH + 16 * h;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(qp + 4 * i);
-            qf[4 * i] = v.x * c; qf[4 * i + 1] = v.y * c; qf[4 * i + 2] = v.z * c; qf[4 * i + 3] = v.w * c;
-        }
-    }
+    Frag<false> qf;
+    load_frag(qf, Q + ((long)b * Lq + (qok ? q : 0)) * ldq + head * DH + 16 * h, c);
     f32x16 o, sA, sB;
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] = 0.f;
@@ -268,25 +299,17 @@ __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
         }
     };
     auto score = [&](int j, f32x16& s) {      // S^T(j) = K_j Q^T
-        const float* ks = Ks(j);
-        float kf[16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(ks + l31 * KP + 16 * h + 4 * i);
-            kf[4 * i] = v.x; kf[4 * i + 1] = v.y; kf[4 * i + 2] = v.z; kf[4 * i + 3] = v.w;
-        }
+        Frag<false> kf;
+        load_frag(kf, Ks(j) + l31 * KP + 16 * h);
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < 16; ++jj) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[jj], qf[jj], s, 0, 0, 0);
+        mma(kf, qf, s);
     };
     auto accumulate = [&](int j, const f32x16& s) {   // O^T += V_j^T P^T
-        const float* vs = Vs(j);
-        float vf[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) vf[e] = vs[acc_row(e, h) * KP + l31];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], s[e], o, 0, 0, 0);
+        Frag<false> vf, pf;
+        load_frag_rows(vf, Vs(j), KP, h, l31);
+        acc_frag(pf, s);
+        mma(vf, pf, o);
     };
     auto softmax = [&](int j, f32x16& s) {
         const int key0 = j * 32;
@@ -339,10 +362,9 @@ __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
 
 }  // namespace
 
-extern "C" int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
-                                float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B,
-                                int Lq, int Lk, int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed,
-                                hipStream_t stream) {
+static int mha_fwd_impl(bool bf16, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                        float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B, int Lq, int Lk,
+                        int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed, hipStream_t stream) {
     SPOT_CHECK_ARG(q && k && v && out, "mha_fwd: null pointer");
     SPOT_CHECK_ARG(head_dim == DH, "mha_fwd: head_dim=%d unsupported (this build handles 32)", head_dim);
     SPOT_CHECK_ARG(B >= 0 && Lq > 0 && Lk > 0 && nhead > 0, "mha_fwd: bad shape B=%d Lq=%d Lk=%d heads=%d", B, Lq, Lk, nhead);
@@ -353,18 +375,41 @@ extern "C" int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long l
     SPOT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mha_fwd: drop_p=%f outside [0,1)", drop_p);
     SPOT_CHECK_ARG(drop_p == 0.f || (Lq <= 65536 && Lk <= 65536), "mha_fwd: dropout needs Lq, Lk <= 65536");
     if (B == 0) return SPOT_OK;
-    // 256-query workgroups need enough of them to fill the chip; short query streams keep the 128-query kernel
-    if (Lq >= 512 && (long)((Lq + 255) / 256) * nhead * B >= 512) {
+    const unsigned thr = spot_drop_threshold(drop_p);
+    const float dscale = 1.f / (1.f - drop_p);
+    if (bf16) {
+        // the matrix work shrinks 16-fold: the loop is vector-bound and gains nothing from pairing matrix with vector phases
+        dim3 grid((Lq + 127) / 128, nhead, B);
+        mha_fwd_kernel<true><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk,
+                                                       nhead, scale, thr, drop_seed, dscale);
+    } else if (Lq >= 512 && (long)((Lq + 255) / 256) * nhead * B >= 512) {
+        // 256-query workgroups need enough of them to fill the chip; short query streams keep the 128-query kernel
         dim3 grid((Lq + 255) / 256, nhead, B);
         mha_fwd_pp_kernel<<<grid, 512, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk, nhead,
-                                                    scale, spot_drop_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
+                                                    scale, thr, drop_seed, dscale);
     } else {
         dim3 grid((Lq + 127) / 128, nhead, B);
-        mha_fwd_kernel<<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk, nhead,
-                                                 scale, spot_drop_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
+        mha_fwd_kernel<false><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk,
+                                                        nhead, scale, thr, drop_seed, dscale);
     }
     SPOT_CHECK_LAUNCH("mha_fwd");
     return SPOT_OK;
+}
+
+extern "C" int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                                float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B,
+                                int Lq, int Lk, int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed,
+                                hipStream_t stream) {
+    return mha_fwd_impl(false, q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, B, Lq, Lk, nhead, head_dim, scale,
+                        drop_p, drop_seed, stream);
+}
+
+extern "C" int spot_mha_fwd_bf16(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                                 float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B,
+                                 int Lq, int Lk, int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed,
+                                 hipStream_t stream) {
+    return mha_fwd_impl(true, q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, B, Lq, Lk, nhead, head_dim, scale,
+                        drop_p, drop_seed, stream);
 }
 
 // ===========================================================================
@@ -404,6 +449,7 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(const float* __restrict_
     }
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
     const float* __restrict__ dO, long lddo, const float* __restrict__ LSE, const float* __restrict__ delta,
@@ -440,18 +486,10 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
         if (kr < Lk) v = *reinterpret_cast<const float4*>(K + ((long)b * Lk + kr) * ldk + head * DH + d4);
         *reinterpret_cast<float4*>(Kt + (f >> 3) * QP + d4) = v;
     }
-    float vf[16], kf[16];
+    Frag<BF16> vf, kf;
     const bool kvalid = key < Lk;
     const bool kdead = !kvalid || (kpm && kpm[(long)b * Lk + key]);
-    {
-        const float* vp = V + ((long)b * Lk + (kvalid ? key : 0)) * ldv + head * DH + 16 * h;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 v = *reinterpret_cast<const float4*>(vp + 4 * i);
-            if (!kvalid) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            vf[4 * i] = v.x; vf[4 * i + 1] = v.y; vf[4 * i + 2] = v.z; vf[4 * i + 3] = v.w;
-        }
-    }
+    load_frag(vf, V + ((long)b * Lk + (kvalid ? key : 0)) * ldv + head * DH + 16 * h, kvalid ? 1.f : 0.f);
     float4 sq, sg;
     float sl = 0.f;
     auto fetch = [&](int t) {
@@ -481,11 +519,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     stash(0);
     __syncthreads();
     // K fragment (B operand of S): lane holds c * K[key][16h .. 16h+15]
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(Kt + (wave * 32 + l31) * QP + 16 * h + 4 * i);
-        kf[4 * i] = v.x * c; kf[4 * i + 1] = v.y * c; kf[4 * i + 2] = v.z * c; kf[4 * i + 3] = v.w * c;
-    }
+    load_frag(kf, Kt + (wave * 32 + l31) * QP + 16 * h, c);
     // From here on the LDS copy of K only feeds dQ = dS K * scale: fold the scale into it once.
     __syncthreads();
 #pragma unroll
@@ -523,18 +557,11 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) dp[e] = drop_thr ? 0.f : -dl[e];
         {
-            float qf[16], gf[16];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 a = *reinterpret_cast<const float4*>(qs + l31 * QP + 16 * h + 4 * i);
-                const float4 g = *reinterpret_cast<const float4*>(gs + l31 * QP + 16 * h + 4 * i);
-                qf[4 * i] = a.x; qf[4 * i + 1] = a.y; qf[4 * i + 2] = a.z; qf[4 * i + 3] = a.w;
-                gf[4 * i] = g.x; gf[4 * i + 1] = g.y; gf[4 * i + 2] = g.z; gf[4 * i + 3] = g.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j], kf[j], s, 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[j], vf[j], dp, 0, 0, 0);
+            Frag<BF16> qf, gf;
+            load_frag(qf, qs + l31 * QP + 16 * h);
+            load_frag(gf, gs + l31 * QP + 16 * h);
+            mma(qf, kf, s);
+            mma(gf, vf, dp);
         }
         // ---- P = exp2(S'), dS = P * dP' (the 1/sqrt(d) factor rides on K and on the final dK); masked or
         //      out-of-range keys contribute nothing
@@ -557,12 +584,16 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) dp[e] *= s[e];
         }
-        // ---- dV += P^T dO ; dK += dS^T Q     (A = accumulator register e, B = row q(e,h) of the LDS tile)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int qr = acc_row(e, h);
-            dv = __builtin_amdgcn_mfma_f32_32x32x2f32(s[e], gs[qr * QP + l31], dv, 0, 0, 0);
-            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[e], qs[qr * QP + l31], dk, 0, 0, 0);
+        // ---- dV += P^T dO ; dK += dS^T Q     (A = the accumulator's 16 query rows, B = those rows of the LDS tile)
+        {
+            Frag<BF16> pf, gf;
+            acc_frag(pf, s);
+            load_frag_rows(gf, gs, QP, h, l31);
+            mma(pf, gf, dv);
+            Frag<BF16> df, qf;
+            acc_frag(df, dp);
+            load_frag_rows(qf, qs, QP, h, l31);
+            mma(df, qf, dk);
         }
         // ---- dQ tile = dS K : transpose dS through this wave's LDS patch
 #pragma unroll
@@ -573,15 +604,11 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[e] = 0.f;
         {
-            float af[16];
+            Frag<BF16> af, bf;
+            load_frag(af, dSs + l31 * QP + 16 * h);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 a = *reinterpret_cast<const float4*>(dSs + l31 * QP + 16 * h + 4 * i);
-                af[4 * i] = a.x; af[4 * i + 1] = a.y; af[4 * i + 2] = a.z; af[4 * i + 3] = a.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                dq = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], Kt[(wave * 32 + 16 * h + j) * QP + l31], dq, 0, 0, 0);
+            for (int j = 0; j < 16; ++j) bf.set(j, Kt[(wave * 32 + 16 * h + j) * QP + l31]);
+            mma(af, bf, dq);
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -604,11 +631,11 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
 
 }  // namespace
 
-extern "C" int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
-                                const float* out, long ldo, const float* d_out, long lddo, const float* lse,
-                                const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq,
-                                float* dk, long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead,
-                                int head_dim, float scale, float drop_p, unsigned drop_seed, hipStream_t stream) {
+static int mha_bwd_impl(bool bf16, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                        const float* out, long ldo, const float* d_out, long lddo, const float* lse,
+                        const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq, float* dk,
+                        long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead, int head_dim, float scale,
+                        float drop_p, unsigned drop_seed, hipStream_t stream) {
     SPOT_CHECK_ARG(q && k && v && out && d_out && lse && delta_ws && dq && dk && dv, "mha_bwd: null pointer");
     SPOT_CHECK_ARG(head_dim == DH, "mha_bwd: head_dim=%d unsupported (this build handles 32)", head_dim);
     SPOT_CHECK_ARG(B >= 0 && Lq > 0 && Lk > 0 && nhead > 0, "mha_bwd: bad shape B=%d Lq=%d Lk=%d heads=%d", B, Lq, Lk, nhead);
@@ -630,11 +657,34 @@ extern "C" int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long l
     mha_delta_kernel<<<(int)((total * 8 + 255) / 256), 256, 0, stream>>>(out, ldo, d_out, lddo, delta_ws, Lq, nhead, total);
     SPOT_CHECK_LAUNCH("mha_bwd(delta)");
     dim3 grid((Lk + 127) / 128, nhead, B);
-    mha_bwd_kernel<<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, d_out, lddo, lse, delta_ws, key_padding_mask, dq,
-                                             lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale,
-                                             spot_drop_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
+    if (bf16)
+        mha_bwd_kernel<true><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, d_out, lddo, lse, delta_ws, key_padding_mask,
+                                                       dq, lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale,
+                                                       spot_drop_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
+    else
+        mha_bwd_kernel<false><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, d_out, lddo, lse, delta_ws, key_padding_mask,
+                                                        dq, lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale,
+                                                        spot_drop_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
     SPOT_CHECK_LAUNCH("mha_bwd");
     return SPOT_OK;
+}
+
+extern "C" int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                                const float* out, long ldo, const float* d_out, long lddo, const float* lse,
+                                const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq,
+                                float* dk, long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead,
+                                int head_dim, float scale, float drop_p, unsigned drop_seed, hipStream_t stream) {
+    return mha_bwd_impl(false, q, ldq, k, ldk, v, ldv, out, ldo, d_out, lddo, lse, key_padding_mask, delta_ws, dq, lddq,
+                        dk, lddk, dv, lddv, B, Lq, Lk, nhead, head_dim, scale, drop_p, drop_seed, stream);
+}
+
+extern "C" int spot_mha_bwd_bf16(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                                 const float* out, long ldo, const float* d_out, long lddo, const float* lse,
+                                 const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq,
+                                 float* dk, long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead,
+                                 int head_dim, float scale, float drop_p, unsigned drop_seed, hipStream_t stream) {
+    return mha_bwd_impl(true, q, ldq, k, ldk, v, ldv, out, ldo, d_out, lddo, lse, key_padding_mask, delta_ws, dq, lddq,
+                        dk, lddk, dv, lddv, B, Lq, Lk, nhead, head_dim, scale, drop_p, drop_seed, stream);
 }
 
 

@@ -49,6 +49,7 @@ class _AttentionParams(nn.Module):
         super().__init__()
         assert d_model % nhead == 0
         self.embed_dim, self.num_heads, self.dropout = d_model, nhead, dropout
+        self.attn_bf16 = False      # bf16 matrix products in the attention core (FeatureFusionNetwork.set_attention_dtype)
         self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
         self.out_proj = _LinearParams(d_model, d_model)
@@ -60,7 +61,7 @@ class _AttentionParams(nn.Module):
         p_attn = self.dropout if self.training else 0.0
         return ops.mha_block(xq, xkv, pos_q, pos_k, self.in_proj_weight, self.in_proj_bias,
                              self.out_proj.weight, self.out_proj.bias, kpm, add_residual, self.num_heads, self_attn,
-                             p_attn, p_out)
+                             p_attn, p_out, self.attn_bf16)
 
 
 def _ffn(x, l1, l2, p=0.0):
@@ -185,6 +186,15 @@ class FeatureFusionNetwork(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
+    def set_attention_dtype(self, dtype):
+        """"f32": exact fp32 attention products; "bf16": bf16 products with fp32 softmax and accumulation."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("attention dtype must be 'f32' or 'bf16', not %r" % (dtype,))
+        for m in self.modules():
+            if isinstance(m, _AttentionParams):
+                m.attn_bf16 = dtype == "bf16"
+        return self
+
     def forward_tokens(self, src_temp, src_search, pos_temp, pos_search, kpm_temp=None, kpm_search=None):
         """Token-level entry: src [B,L,C], pos [R,C]; returns hs [B, Ls, C]."""
         mem_t, mem_s = self.encoder(src_temp, src_search, kpm_temp, kpm_search, pos_temp, pos_search)
@@ -197,10 +207,11 @@ class FeatureFusionNetwork(nn.Module):
 
 
 def build_featurefusion_network(settings):
-    return FeatureFusionNetwork(
+    net = FeatureFusionNetwork(
         d_model=settings.hidden_dim,
         dropout=settings.dropout,
         nhead=settings.nheads,
         dim_feedforward=settings.dim_feedforward,
         num_featurefusion_layers=settings.featurefusion_layers,
     )
+    return net.set_attention_dtype(getattr(settings, "attention_dtype", "f32"))

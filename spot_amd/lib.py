@@ -60,6 +60,9 @@ SIGNATURES = {
     "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
     "spot_mha_bwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64,
                          i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
+    "spot_mha_fwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
+    "spot_mha_bwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64,
+                         i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
     "spot_mha_dropout_mask": [vp, i32, i32, i32, i32, f32, C.c_uint, vp],
     "spot_dropout_f32": [vp, vp, i64, i32, f32, C.c_uint, vp],
     "spot_layernorm_fwd_f32": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],

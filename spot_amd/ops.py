@@ -540,12 +540,13 @@ def layer_norm_infer(x, gamma, beta, eps=1e-5):
 # ---------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------
-def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, out=None, drop_p=0.0, drop_seed=0):
+def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, out=None, drop_p=0.0, drop_seed=0,
+                 bf16=False):
     dev = q.device
     if out is None:
         out = torch.empty((B * Lq, nhead * dh), dtype=torch.float32, device=dev)
     lse = torch.empty((B, nhead, Lq), dtype=torch.float32, device=dev) if want_lse else None
-    launch = lambda: lib.call("spot_mha_fwd_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), out.stride(0), _p(lse),
+    launch = lambda: lib.call("spot_mha_fwd_bf16" if bf16 else "spot_mha_fwd_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), out.stride(0), _p(lse),
                               _p(kpm), B, Lq, Lk, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), drop_seed, _st())
     if TIMER is not None:
         TIMER.run("mha_fwd Lq%d Lk%d B%d" % (Lq, Lk, B) if TIMER.shapes else "mha_fwd", 4.0 * B * nhead * Lq * Lk * dh, launch)
@@ -582,7 +583,7 @@ class MHAFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn,
-                p_attn=0.0, p_out=0.0):
+                p_attn=0.0, p_out=0.0, bf16=False):
         B, Lq, Cn = xq.shape
         Lk = xkv.shape[1]
         dh = Cn // nhead
@@ -610,12 +611,13 @@ class MHAFn(torch.autograd.Function):
         sa = next_seed() if p_attn > 0 else 0
         so = next_seed() if p_out > 0 else 0
         attn, lse = mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, need_grad, drop_p=p_attn,
-                                 drop_seed=sa)
+                                 drop_seed=sa, bf16=bf16)
         z = linear_fwd(attn, out_w, out_b, residual=xq2 if add_residual else None, drop_p=p_out, drop_seed=so)
         if need_grad:
             ctx.save_for_backward(xq2, xkv2, pos_q, pos_k, in_w, out_w, qkv, kv, attn, lse, kpm)
             ctx.dims = (B, Lq, Lk, Cn, nhead, dh, self_attn, bool(add_residual))
             ctx.drop = (p_attn, sa, p_out, so)
+            ctx.bwd_entry = "spot_mha_bwd_bf16" if bf16 else "spot_mha_bwd_f32"
             ctx.params = (in_w, in_b, out_w, out_b)
         return z.view(B, Lq, Cn)
 
@@ -639,7 +641,7 @@ class MHAFn(torch.autograd.Function):
         if self_attn:
             dqkv = torch.empty_like(qkv)
             _timed_mha_bwd(B, Lq, Lk, nhead, dh, lambda: lib.call(
-                "spot_mha_bwd_f32", _p(qkv), 3 * Cn, _p(qkv[:, Cn:]), 3 * Cn, _p(qkv[:, 2 * Cn:]), 3 * Cn,
+                ctx.bwd_entry, _p(qkv), 3 * Cn, _p(qkv[:, Cn:]), 3 * Cn, _p(qkv[:, 2 * Cn:]), 3 * Cn,
                 _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
                 _p(dqkv), 3 * Cn, _p(dqkv[:, Cn:]), 3 * Cn, _p(dqkv[:, 2 * Cn:]), 3 * Cn,
                 B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _st()))
@@ -655,7 +657,7 @@ class MHAFn(torch.autograd.Function):
             dq = torch.empty_like(qkv)
             dkv = torch.empty_like(kv)
             _timed_mha_bwd(B, Lq, Lk, nhead, dh, lambda: lib.call(
-                "spot_mha_bwd_f32", _p(qkv), Cn, _p(kv), 2 * Cn, _p(kv[:, Cn:]), 2 * Cn,
+                ctx.bwd_entry, _p(qkv), Cn, _p(kv), 2 * Cn, _p(kv[:, Cn:]), 2 * Cn,
                 _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
                 _p(dq), Cn, _p(dkv), 2 * Cn, _p(dkv[:, Cn:]), 2 * Cn,
                 B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _st()))
@@ -674,10 +676,11 @@ class MHAFn(torch.autograd.Function):
         pg = [None if sk is not None else g for sk, g in zip(sinks, (d_in_w, d_in_b, d_out_w, d_out_b))]
         # self-attention: xq and xkv are the same tensor, the whole gradient goes to xq
         return (dxq.view(B, Lq, Cn), None if self_attn else dxkv.view(B, Lk, Cn), None, None, *pg, None, None, None,
-                None, None, None)
+                None, None, None, None)
 
 
 def mha_block(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn,
-              p_attn=0.0, p_out=0.0):
+              p_attn=0.0, p_out=0.0, bf16=False):
+    """bf16=True takes the attention core's matrix products in bf16 (fp32 softmax and accumulation)."""
     return MHAFn.apply(xq, xkv, pos_q, pos_k, in_w, in_b, out_w, out_b, kpm, add_residual, nhead, self_attn,
-                       p_attn, p_out)
+                       p_attn, p_out, bf16)

@@ -290,6 +290,41 @@ def test_mha_core_fwd_bwd(ops, Lq, Lk):
     np.testing.assert_allclose(dv.view(B, Lk, C).cpu().numpy(), vc.grad.numpy(), rtol=2e-4, atol=2e-5)
 
 
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm()))
+
+
+@pytest.mark.parametrize("Lq,Lk", [(256, 256), (1024, 256), (256, 1024), (50, 77)])
+def test_mha_core_bf16_products_track_fp32(ops, Lq, Lk):
+    """bf16 matrix products with fp32 softmax/accumulation: within bf16 rounding of the exact result
+    (outputs 1e-2 of their scale; gradients by cosine >= 0.999, the bar of the bf16 training configuration)."""
+    from spot_amd import lib as L
+    B, nh, dh = 2, 4, 32
+    C = nh * dh
+    q, k, v = (det_input(n, (B, L_, C), 1, -2, 2) for n, L_ in (("q", Lq), ("k", Lk), ("v", Lk)))
+    do = det_input("do", (B, Lq, C), 2, -1, 1)
+    kpm = np.zeros((B, Lk), bool)
+    kpm[1, Lk // 2:Lk // 2 + 5] = True
+    qg, kg, vg, kp = G(q).view(-1, C), G(k).view(-1, C), G(v).view(-1, C), G(kpm.astype(np.uint8))
+    out, lse = ops.mha_core_fwd(qg, C, kg, C, vg, C, B, Lq, Lk, nh, dh, kp, True, bf16=True)
+    qc, kc, vc = (T(a).double().requires_grad_() for a in (q, k, v))
+    ref = _ref_attn(qc, kc, vc, T(kpm), nh)
+    o = out.view(B, Lq, C).cpu()
+    assert float((o - ref.detach()).abs().max()) <= 1e-2 * float(ref.detach().abs().max())
+    assert _cos(o, ref.detach()) > 0.9999
+    (ref * T(do).double()).sum().backward()
+    dq, dk, dv = torch.empty_like(qg), torch.empty_like(kg), torch.empty_like(vg)
+    delta = torch.empty((B, nh, Lq), device=DEV)
+    dog = G(do).view(-1, C)
+    P = ops._p
+    L.call("spot_mha_bwd_bf16", P(qg), C, P(kg), C, P(vg), C, P(out), C, P(dog), C, P(lse), P(kp), P(delta),
+           P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), 0.0, 0, ops._st())
+    for got, want in ((dq, qc.grad), (dk, kc.grad), (dv, vc.grad)):
+        assert _cos(got.cpu(), want) > 0.999
+        assert float((got.cpu().view_as(want) - want).abs().max()) <= 3e-2 * float(want.abs().max())
+
+
 # --------------------------------------------------------------------------- fusion network
 def _load_det(module, seed):
     from spot_amd.detinit import det_fill_

@@ -96,6 +96,34 @@ def test_student_step_golden(golden):
                                    atol=2e-3 * max(1e-6, float(np.abs(ref).max())), err_msg=k)
 
 
+def test_student_step_bf16_attention_tracks_fp32(golden):
+    """Training configuration with bf16 attention products (fp32 softmax/accumulate, fp32 elsewhere): loss within
+    1e-2 relative of the reference's fp32 loss, gradients within cosine 0.999 of the fp32 run's."""
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.criterion import transt_loss
+    from spot_amd.tensordict import TensorDict
+    from tests.test_oracle_model import student_batches
+    g = golden("g15_student")
+    seed, bs, bu = int(g["seed"]), int(g["bs"]), int(g["bu"])
+    S = Settings(dropout=0.0)
+    grads, losses = [], []
+    for dtype in ("f32", "bf16"):
+        net = build(seed, dropout=0.0).train()
+        net.featurefusion_network.set_attention_dtype(dtype)
+        actor = TranstSparseActor(S, net, net, transt_loss(S))
+        sup, sp = student_batches(seed, bs, bu)
+        sup = TensorDict({k: v.to(DEV) for k, v in sup.items()})
+        sp = TensorDict({k: v.to(DEV) for k, v in sp.items()})
+        loss, _ = actor(mode="spsup", burnin_data=sup, sp_data=sp)
+        loss.backward()
+        losses.append(loss.item())
+        grads.append(torch.cat([p.grad.flatten() for _, p in net.named_parameters() if p.grad is not None]))
+    np.testing.assert_allclose(losses[1], float(g["loss"]), rtol=1e-2)
+    cos = float((grads[0].double() @ grads[1].double()) / (grads[0].double().norm() * grads[1].double().norm()))
+    assert cos >= 0.999, cos
+    assert not torch.equal(grads[0], grads[1])          # the bf16 path really ran
+
+
 def test_gradient_sinks_match_autograd_accumulation(golden):
     """Gradients added into the flat buffer by the kernels equal the ones autograd accumulates, and a
     second backward adds on top (the trainer zeroes the buffer once per step)."""

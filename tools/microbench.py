@@ -76,14 +76,15 @@ def bench_gemm():
 
 def bench_mha(shapes=((1024, 1024), (256, 256), (256, 1024), (1024, 256)), iters=20):
     pd = float(os.environ.get("SPOT_MB_DROP", "0"))
-    print("== mha core (fp32 MFMA), attention dropout %g" % pd)
+    bf16 = os.environ.get("SPOT_MB_BF16", "0") == "1"
+    print("== mha core (%s MFMA), attention dropout %g" % ("bf16" if bf16 else "fp32", pd))
     B, H, dh = 40, 8, 32
     C = H * dh
     for Lq, Lk in shapes:
         q, k, v = r(B * Lq, C), r(B * Lk, C), r(B * Lk, C)
         out, lse = ops.mha_core_fwd(q, C, k, C, v, C, B, Lq, Lk, H, dh, None, True)
         t = timeit(lambda: ops.mha_core_fwd(q, C, k, C, v, C, B, Lq, Lk, H, dh, None, True, out=out, drop_p=pd,
-                                            drop_seed=7), iters)
+                                            drop_seed=7, bf16=bf16), iters)
         fl = 4.0 * B * H * Lq * Lk * dh
         do = r(B * Lq, C)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -91,7 +92,7 @@ def bench_mha(shapes=((1024, 1024), (256, 256), (256, 1024), (1024, 256)), iters
         P = ops._p
 
         def bwd():
-            lib.call("spot_mha_bwd_f32", P(q), C, P(k), C, P(v), C, P(out), C, P(do), C, P(lse), None, P(delta),
+            lib.call("spot_mha_bwd_bf16" if bf16 else "spot_mha_bwd_f32", P(q), C, P(k), C, P(v), C, P(out), C, P(do), C, P(lse), None, P(delta),
                      P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, H, dh, 1.0 / math.sqrt(dh), pd, 7, ops._st())
         tb = timeit(bwd, iters)
         print("Lq=%4d Lk=%4d  fwd %8.1f us %6.1f TF | bwd %8.1f us %6.1f TF" %
