@@ -240,6 +240,28 @@ int spot_groupdw_bwd_f32(const float* x11, const float* x12, const float* x21, c
                          float* dsoftmax_partial, int planes, int hx, int wx, int hz, int wz,
                          hipStream_t stream);
 
+/* ---- BatchNorm2d fused with the ReLU / residual add that follow it in the ResNet bottleneck
+ * (ltr/models/backbone/resnet.py:72-92,196-198), NCHW fp32, HW a multiple of 4.
+ * Training forward: batch statistics over (N, HW) per channel; y = [relu]((x - mean) rstd gamma + beta [+ residual]);
+ * running_mean / running_var updated with `momentum` (unbiased variance), *num_batches_tracked += 1 (all three may be
+ * NULL); save_mean / save_rstd [C] for backward; relu_sign [N*C*HW/4] bytes (bit j = element j of the float4 passed
+ * the ReLU; NULL when no gradient is needed).  ws: spot_batchnorm_ws_floats(N, C) floats. */
+long spot_batchnorm_ws_floats(int N, int C);
+int spot_batchnorm_fwd_train_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, long long* num_batches_tracked, float* y,
+                                 float* save_mean, float* save_rstd, unsigned char* relu_sign, float* ws, int N,
+                                 int C, int HW, float eps, float momentum, int relu, hipStream_t stream);
+/* Inference forward with the running statistics (one pass). */
+int spot_batchnorm_fwd_infer_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                                 const float* running_mean, const float* running_var, float* y, int N, int C,
+                                 int HW, float eps, int relu, hipStream_t stream);
+/* Backward of the training forward.  dy is the gradient of the fused output; relu_sign as written by forward (NULL
+ * if no ReLU was fused).  dx: gradient w.r.t. x; d_residual (may be NULL): gradient w.r.t. the residual input
+ * (= dy gated by the ReLU); dgamma / dbeta [C] overwritten, or added to when accumulate != 0. */
+int spot_batchnorm_bwd_f32(const float* dy, const float* x, const unsigned char* relu_sign, const float* save_mean,
+                           const float* save_rstd, const float* gamma, float* dx, float* d_residual, float* dgamma,
+                           float* dbeta, float* ws, int N, int C, int HW, int accumulate, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

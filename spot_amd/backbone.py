@@ -4,10 +4,12 @@ Mirror of ltr/models/backbone/resnet.py:56-92,95-205 and
 ltr/models/backbone/transt_backbone.py:55-106 with identical state-dict keys
 (`backbone.0.body.conv1.weight`, `...layer3.5.bn3.running_var`, ...).
 
-The dense 3x3/1x1 convolutions and BatchNorm of the ResNet run through
-PyTorch-ROCm (MIOpen) — the one part of the path that is not a hand-written
-kernel yet.  Everything downstream (projection, fusion, heads, decode, filter)
-is libspot_hip.so.
+The dense 3x3/1x1 convolutions of the ResNet run through PyTorch-ROCm (MIOpen) —
+the one part of the path that is not a hand-written kernel yet.  BatchNorm is
+fused with the ReLU / residual add that follow it (batchnorm.hip); everything
+downstream (projection, fusion, heads, decode, filter) is libspot_hip.so.
+The nn.BatchNorm2d modules remain as parameter/buffer holders so state-dict
+keys match the reference.
 """
 import math
 
@@ -15,6 +17,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import ops
 from .tensordict import NestedTensor
 
 
@@ -35,11 +38,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        residual = x if self.downsample is None else self.downsample(x)
-        return self.relu(out + residual)
+        out = ops.batch_norm_act(self.conv1(x), self.bn1, relu=True)
+        out = ops.batch_norm_act(self.conv2(out), self.bn2, relu=True)
+        residual = x if self.downsample is None else ops.batch_norm_act(self.downsample[0](x), self.downsample[1])
+        return ops.batch_norm_act(self.conv3(out), self.bn3, relu=True, residual=residual)
 
 
 class ResNet50Layer3(nn.Module):
@@ -77,7 +79,7 @@ class ResNet50Layer3(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(ops.batch_norm_act(self.conv1(x), self.bn1, relu=True))
         return self.layer3(self.layer2(self.layer1(x)))
 
 

@@ -1,0 +1,291 @@
+// BatchNorm2d fused with what follows it in the ResNet bottleneck
+// (ltr/models/backbone/resnet.py:72-92: bn -> relu, and bn3 -> += residual -> relu;
+// stem :196-198), NCHW fp32.
+//
+// All three are HBM-bound.  The reference's eager sequence reads and writes the
+// activation once per op (batch_norm: 2 reads + 1 write, relu: 1 + 1, residual add:
+// 2 + 1); here a layer is
+//   training forward : stats pass (1 read)  +  apply pass (1 read [+ residual] , 1 write, 1/16 write of a sign byte)
+//   training backward: reduce pass (dy, x, sign byte)  +  apply pass (dy, x, sign byte -> dx [, d_residual])
+//   inference        : one pass
+// Statistics are accumulated around a per-channel shift (the channel's first element),
+// which keeps E[(x-K)^2] - E[x-K]^2 free of cancellation without a second read.
+// One workgroup owns a (channel, slice of the batch) pair; slices of a channel are
+// combined by every consumer workgroup from the per-slice partials (at most 64 pairs),
+// so there is no finalize launch and no atomics: results are bit-reproducible.
+#include "common.h"
+#include "../../include/spot_hip.h"
+
+namespace {
+
+constexpr int MAX_SPLIT = 64;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {   // red: 4 floats of LDS; all threads get the sum
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+struct Slice {
+    int n0, n1;
+};
+// thread's next float4 of the (sample, position) walk: 256 positions further, wrapping into the next samples
+__device__ __forceinline__ void advance(int& n, int& i, int HW4) {
+    i += 256;
+    while (i >= HW4) {
+        i -= HW4;
+        ++n;
+    }
+}
+__device__ __forceinline__ Slice slice_of(int N, int S, int s) {
+    const int base = N / S, rem = N % S;
+    Slice r;
+    r.n0 = s * base + min(s, rem);
+    r.n1 = r.n0 + base + (s < rem ? 1 : 0);
+    return r;
+}
+
+// ---- pass 1 (training): shifted sum and sum of squares per (channel, slice)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial, int N,
+                                                       int C, int HW4, int S) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, s = blockIdx.y;
+    const Slice sl = slice_of(N, S, s);
+    const float K = x[(size_t)c * HW4 * 4];
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = sl.n0 + (int)threadIdx.x / HW4, i = (int)threadIdx.x % HW4; n < sl.n1; advance(n, i, HW4)) {
+        const float4 v = reinterpret_cast<const float4*>(x)[((size_t)n * C + c) * HW4 + i];
+        const float a = v.x - K, b = v.y - K, d = v.z - K, e = v.w - K;
+        s1 += (a + b) + (d + e);
+        s2 += (a * a + b * b) + (d * d + e * e);
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        partial[((size_t)c * S + s) * 2] = s1;
+        partial[((size_t)c * S + s) * 2 + 1] = s2;
+    }
+}
+
+// combine the S partial pairs of channel c (every thread returns the totals)
+__device__ __forceinline__ void combine(const float* __restrict__ partial, int c, int S, float& a, float& b, float* red) {
+    float pa = 0.f, pb = 0.f;
+    if ((int)threadIdx.x < S) {
+        pa = partial[((size_t)c * S + threadIdx.x) * 2];
+        pb = partial[((size_t)c * S + threadIdx.x) * 2 + 1];
+    }
+    a = block_sum(pa, red);
+    b = block_sum(pb, red);
+}
+
+// ---- pass 2 (training): normalise, affine, (+ residual), (relu), sign byte
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                       const float* __restrict__ partial,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                       long long* __restrict__ tracked, float* __restrict__ y,
+                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                       unsigned char* __restrict__ sign, int N, int C, int HW4, int S,
+                                                       float eps, float momentum) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, s = blockIdx.y;
+    float s1, s2;
+    combine(partial, c, S, s1, s2, red);
+    const float M = (float)N * (float)(HW4 * 4);
+    const float K = x[(size_t)c * HW4 * 4];
+    const float dm = s1 / M;
+    const float mean = K + dm;
+    const float var = fmaxf(s2 / M - dm * dm, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    if (s == 0 && threadIdx.x == 0) {
+        save_mean[c] = mean;
+        save_rstd[c] = rstd;
+        if (run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * (var * (M / (M - 1.f)));
+        }
+        if (tracked && c == 0) *tracked += 1;
+    }
+    const float a = rstd * gamma[c], b = beta[c] - mean * a;
+    const Slice sl = slice_of(N, S, s);
+    for (int n = sl.n0 + (int)threadIdx.x / HW4, i = (int)threadIdx.x % HW4; n < sl.n1; advance(n, i, HW4)) {
+        const size_t off = ((size_t)n * C + c) * HW4 + i;
+        const float4 v = reinterpret_cast<const float4*>(x)[off];
+        float4 o = make_float4(fmaf(v.x, a, b), fmaf(v.y, a, b), fmaf(v.z, a, b), fmaf(v.w, a, b));
+        if (RES) {
+            const float4 r = reinterpret_cast<const float4*>(res)[off];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (RELU) {
+            if (sign) sign[off] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        reinterpret_cast<float4*>(y)[off] = o;
+    }
+}
+
+// ---- inference: one pass with the running statistics
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_infer_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                                       float* __restrict__ y, int N, int C, int HW4, int S, float eps) {
+    const int c = blockIdx.x, s = blockIdx.y;
+    const float a = gamma[c] / sqrtf(run_var[c] + eps), b = beta[c] - run_mean[c] * a;
+    const Slice sl = slice_of(N, S, s);
+    for (int n = sl.n0 + (int)threadIdx.x / HW4, i = (int)threadIdx.x % HW4; n < sl.n1; advance(n, i, HW4)) {
+        const size_t off = ((size_t)n * C + c) * HW4 + i;
+        const float4 v = reinterpret_cast<const float4*>(x)[off];
+        float4 o = make_float4(fmaf(v.x, a, b), fmaf(v.y, a, b), fmaf(v.z, a, b), fmaf(v.w, a, b));
+        if (RES) {
+            const float4 r = reinterpret_cast<const float4*>(res)[off];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        reinterpret_cast<float4*>(y)[off] = o;
+    }
+}
+
+__device__ __forceinline__ float4 gate(float4 g, unsigned m) {
+    return make_float4((m & 1) ? g.x : 0.f, (m & 2) ? g.y : 0.f, (m & 4) ? g.z : 0.f, (m & 8) ? g.w : 0.f);
+}
+
+// ---- backward pass 1: sum g and sum g * xhat per (channel, slice), g = dy gated by the sign byte
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const unsigned char* __restrict__ sign,
+                                                            const float* __restrict__ save_mean,
+                                                            const float* __restrict__ save_rstd, float* __restrict__ partial,
+                                                            int N, int C, int HW4, int S) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, s = blockIdx.y;
+    const float mean = save_mean[c], rstd = save_rstd[c];
+    const Slice sl = slice_of(N, S, s);
+    float sb = 0.f, sg = 0.f;
+    for (int n = sl.n0 + (int)threadIdx.x / HW4, i = (int)threadIdx.x % HW4; n < sl.n1; advance(n, i, HW4)) {
+        const size_t off = ((size_t)n * C + c) * HW4 + i;
+        float4 g = reinterpret_cast<const float4*>(dy)[off];
+        if (sign) g = gate(g, sign[off]);
+        const float4 v = reinterpret_cast<const float4*>(x)[off];
+        sb += (g.x + g.y) + (g.z + g.w);
+        sg += (g.x * (v.x - mean) + g.y * (v.y - mean)) + (g.z * (v.z - mean) + g.w * (v.w - mean));
+    }
+    sb = block_sum(sb, red);
+    sg = block_sum(sg, red);
+    if (threadIdx.x == 0) {
+        partial[((size_t)c * S + s) * 2] = sb;
+        partial[((size_t)c * S + s) * 2 + 1] = sg * rstd;
+    }
+}
+
+// ---- backward pass 2: dx = gamma rstd (g - dbeta/M - xhat dgamma/M); d_residual = g
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const unsigned char* __restrict__ sign,
+                                                           const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ partial,
+                                                           float* __restrict__ dx, float* __restrict__ dres,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
+                                                           int C, int HW4, int S, int accumulate) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, s = blockIdx.y;
+    float db, dg;
+    combine(partial, c, S, db, dg, red);
+    if (s == 0 && threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
+    }
+    const float mean = save_mean[c], rstd = save_rstd[c];
+    const float M = (float)N * (float)(HW4 * 4);
+    const float k = gamma[c] * rstd, kb = db / M, kg = dg * rstd / M;
+    const Slice sl = slice_of(N, S, s);
+    for (int n = sl.n0 + (int)threadIdx.x / HW4, i = (int)threadIdx.x % HW4; n < sl.n1; advance(n, i, HW4)) {
+        const size_t off = ((size_t)n * C + c) * HW4 + i;
+        float4 g = reinterpret_cast<const float4*>(dy)[off];
+        if (sign) g = gate(g, sign[off]);
+        const float4 v = reinterpret_cast<const float4*>(x)[off];
+        if (dres) reinterpret_cast<float4*>(dres)[off] = g;
+        reinterpret_cast<float4*>(dx)[off] = make_float4(k * (g.x - kb - (v.x - mean) * kg), k * (g.y - kb - (v.y - mean) * kg),
+                                                         k * (g.z - kb - (v.z - mean) * kg), k * (g.w - kb - (v.w - mean) * kg));
+    }
+}
+
+int split_for(int N, int C) {
+    int S = 2048 / C;
+    if (S < 1) S = 1;
+    if (S > N) S = N;
+    if (S > MAX_SPLIT) S = MAX_SPLIT;
+    return S;
+}
+
+bool shape_ok(int N, int C, int HW) { return N > 0 && C > 0 && HW > 0 && HW % 4 == 0 && C <= 65535; }
+
+}  // namespace
+
+extern "C" long spot_batchnorm_ws_floats(int N, int C) { return (long)C * split_for(N > 0 ? N : 1, C > 0 ? C : 1) * 2; }
+
+extern "C" int spot_batchnorm_fwd_train_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                                            float* running_mean, float* running_var, long long* num_batches_tracked,
+                                            float* y, float* save_mean, float* save_rstd, unsigned char* relu_sign,
+                                            float* ws, int N, int C, int HW, float eps, float momentum, int relu,
+                                            hipStream_t stream) {
+    SPOT_CHECK_ARG(shape_ok(N, C, HW), "batchnorm_fwd_train: bad shape N=%d C=%d HW=%d (HW must be a multiple of 4)", N, C, HW);
+    SPOT_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd && ws, "batchnorm_fwd_train: null pointer");
+    SPOT_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "batchnorm_fwd_train: running stats come in pairs");
+    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0, "batchnorm_fwd_train: 16-byte alignment");
+    SPOT_CHECK_ARG(relu || !relu_sign, "batchnorm_fwd_train: a sign buffer only makes sense with relu");
+    const int S = split_for(N, C);
+    dim3 grid(C, S);
+    bn_stats_kernel<<<grid, 256, 0, stream>>>(x, ws, N, C, HW / 4, S);
+    SPOT_CHECK_LAUNCH("batchnorm_fwd_train(stats)");
+#define SPOT_BN_APPLY(R, A)                                                                                             \
+    bn_apply_kernel<R, A><<<grid, 256, 0, stream>>>(x, residual, ws, gamma, beta, running_mean, running_var,             \
+                                                    num_batches_tracked, y, save_mean, save_rstd, relu_sign, N, C, HW / 4, \
+                                                    S, eps, momentum)
+    if (relu && residual) SPOT_BN_APPLY(true, true);
+    else if (relu) SPOT_BN_APPLY(true, false);
+    else if (residual) SPOT_BN_APPLY(false, true);
+    else SPOT_BN_APPLY(false, false);
+#undef SPOT_BN_APPLY
+    SPOT_CHECK_LAUNCH("batchnorm_fwd_train(apply)");
+    return SPOT_OK;
+}
+
+extern "C" int spot_batchnorm_fwd_infer_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                                            const float* running_mean, const float* running_var, float* y, int N, int C,
+                                            int HW, float eps, int relu, hipStream_t stream) {
+    SPOT_CHECK_ARG(shape_ok(N, C, HW), "batchnorm_fwd_infer: bad shape N=%d C=%d HW=%d (HW must be a multiple of 4)", N, C, HW);
+    SPOT_CHECK_ARG(x && gamma && beta && running_mean && running_var && y, "batchnorm_fwd_infer: null pointer");
+    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0, "batchnorm_fwd_infer: 16-byte alignment");
+    const int S = split_for(N, C);
+    dim3 grid(C, S);
+#define SPOT_BN_INFER(R, A) \
+    bn_infer_kernel<R, A><<<grid, 256, 0, stream>>>(x, residual, gamma, beta, running_mean, running_var, y, N, C, HW / 4, S, eps)
+    if (relu && residual) SPOT_BN_INFER(true, true);
+    else if (relu) SPOT_BN_INFER(true, false);
+    else if (residual) SPOT_BN_INFER(false, true);
+    else SPOT_BN_INFER(false, false);
+#undef SPOT_BN_INFER
+    SPOT_CHECK_LAUNCH("batchnorm_fwd_infer");
+    return SPOT_OK;
+}
+
+extern "C" int spot_batchnorm_bwd_f32(const float* dy, const float* x, const unsigned char* relu_sign,
+                                      const float* save_mean, const float* save_rstd, const float* gamma, float* dx,
+                                      float* d_residual, float* dgamma, float* dbeta, float* ws, int N, int C, int HW,
+                                      int accumulate, hipStream_t stream) {
+    SPOT_CHECK_ARG(shape_ok(N, C, HW), "batchnorm_bwd: bad shape N=%d C=%d HW=%d (HW must be a multiple of 4)", N, C, HW);
+    SPOT_CHECK_ARG(dy && x && save_mean && save_rstd && gamma && dx && ws, "batchnorm_bwd: null pointer");
+    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)d_residual) & 15) == 0,
+                   "batchnorm_bwd: 16-byte alignment");
+    const int S = split_for(N, C);
+    dim3 grid(C, S);
+    bn_bwd_reduce_kernel<<<grid, 256, 0, stream>>>(dy, x, relu_sign, save_mean, save_rstd, ws, N, C, HW / 4, S);
+    SPOT_CHECK_LAUNCH("batchnorm_bwd(reduce)");
+    bn_bwd_apply_kernel<<<grid, 256, 0, stream>>>(dy, x, relu_sign, save_mean, save_rstd, gamma, ws, dx, d_residual, dgamma,
+                                                  dbeta, N, C, HW / 4, S, accumulate);
+    SPOT_CHECK_LAUNCH("batchnorm_bwd(apply)");
+    return SPOT_OK;
+}

@@ -55,6 +55,9 @@ SIGNATURES = {
     "spot_groupdw_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "spot_xcorr_depthwise_bwd_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "spot_groupdw_bwd_f32": [vp] * 15 + [i32, i32, i32, i32, i32, vp],
+    "spot_batchnorm_fwd_train_f32": [vp] * 12 + [i32, i32, i32, f32, f32, i32, vp],
+    "spot_batchnorm_fwd_infer_f32": [vp] * 7 + [i32, i32, i32, f32, i32, vp],
+    "spot_batchnorm_bwd_f32": [vp] * 11 + [i32, i32, i32, i32, vp],
     "spot_gemm_f32": [C.POINTER(GemmDesc), vp],
     "spot_colsum_f32": [vp, i64, vp, i64, i32, vp],
     "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
@@ -88,6 +91,8 @@ def load():
     lib.spot_last_error.argtypes = []
     lib.spot_layernorm_bwd_ws_floats.restype = i64
     lib.spot_layernorm_bwd_ws_floats.argtypes = [i64, i32]
+    lib.spot_batchnorm_ws_floats.restype = i64
+    lib.spot_batchnorm_ws_floats.argtypes = [i32, i32]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.restype = i32

@@ -538,6 +538,80 @@ def layer_norm_infer(x, gamma, beta, eps=1e-5):
 
 
 # ---------------------------------------------------------------------------
+# BatchNorm2d + ReLU (+ residual) of the ResNet bottleneck
+# ---------------------------------------------------------------------------
+class BatchNormActFn(torch.autograd.Function):
+    """y = [relu](batch_norm(x) [+ residual]) in training mode (batch statistics, running stats updated)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, tracked, eps, momentum, relu):
+        x = _chk(x.contiguous())
+        N, Cn, H, W = x.shape
+        HW = H * W
+        if residual is not None:
+            residual = _chk(residual.contiguous())
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty((Cn,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((Cn,), dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad)
+        sign = torch.empty((x.numel() // 4,), dtype=torch.uint8, device=dev) if (relu and need) else None
+        ws = torch.empty((lib.load().spot_batchnorm_ws_floats(N, Cn),), dtype=torch.float32, device=dev)
+        lib.call("spot_batchnorm_fwd_train_f32", _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean),
+                 _p(running_var), _p(tracked), _p(y), _p(mean), _p(rstd), _p(sign), _p(ws), N, Cn, HW, float(eps),
+                 float(momentum), int(relu), _st())
+        if need:
+            ctx.save_for_backward(x, sign, mean, rstd, gamma)
+            ctx.params = (gamma, beta)
+            ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sign, mean, rstd, gamma = ctx.saved_tensors
+        pg, pb = ctx.params
+        N, Cn, H, W = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        sg, sb = _sink(pg), _sink(pb)
+        direct = sg is not None and sb is not None
+        dg = sg if direct else torch.empty_like(gamma)
+        db = sb if direct else torch.empty_like(gamma)
+        ws = torch.empty((lib.load().spot_batchnorm_ws_floats(N, Cn),), dtype=torch.float32, device=dy.device)
+        lib.call("spot_batchnorm_bwd_f32", _p(dy), _p(x), _p(sign), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dres),
+                 _p(dg), _p(db), _p(ws), N, Cn, H * W, int(direct), _st())
+        if direct:
+            _sink_done(pg, pb)
+            dg = db = None
+        return dx, dres, dg, db, None, None, None, None, None, None
+
+
+def batch_norm_act(x, bn, relu=False, residual=None):
+    """nn.BatchNorm2d `bn` applied to x, then (+ residual) and (ReLU), as one fused op.
+    Training mode uses batch statistics and updates bn's running buffers like the module would."""
+    if x.shape[2] * x.shape[3] % 4 != 0:
+        raise RuntimeError("spot_amd: fused BatchNorm needs H*W to be a multiple of 4, got %dx%d" % tuple(x.shape[2:]))
+    if bn.training or not bn.track_running_stats:
+        if bn.momentum is None:
+            raise RuntimeError("spot_amd: cumulative-average BatchNorm (momentum=None) is not supported")
+        track = bn.track_running_stats
+        return BatchNormActFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean if track else None,
+                                    bn.running_var if track else None, bn.num_batches_tracked if track else None,
+                                    bn.eps, bn.momentum, relu)
+    x = _chk(x.contiguous())
+    if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
+        raise RuntimeError("spot_amd: BatchNorm in eval mode is an inference path here; wrap it in torch.no_grad()")
+    N, Cn, H, W = x.shape
+    y = torch.empty_like(x)
+    if residual is not None:
+        residual = _chk(residual.contiguous())
+    lib.call("spot_batchnorm_fwd_infer_f32", _p(x), _p(residual), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
+             _p(bn.running_var), _p(y), N, Cn, H * W, float(bn.eps), int(relu), _st())
+    return y
+
+
+# ---------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------
 def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, out=None, drop_p=0.0, drop_seed=0,

@@ -519,3 +519,42 @@ def test_xcorr_backward_golden(ops, golden):
         (oc.view(B, C, *oc.shape[2:]) * T(up).double()).sum().backward()
         np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(zg.grad.cpu().numpy(), zc.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(3, 64, 16, 16), (5, 8, 6, 6), (2, 2048, 4, 4), (40, 16, 64, 64)])
+def test_batch_norm_act_fwd_bwd_vs_torch(ops, N, C, H, W):
+    """Fused BatchNorm (+ residual) (+ ReLU) in training and inference mode against nn.BatchNorm2d / F.relu in fp64."""
+    x, r = det_input("x", (N, C, H, W), 3, -2, 3), det_input("r", (N, C, H, W), 4, -1, 1)
+    gm, bt = det_input("g", (C,), 5, 0.5, 1.5), det_input("b", (C,), 6, -0.5, 0.5)
+    up = det_input("up", (N, C, H, W), 7, -1, 1)
+    for relu, use_res in ((True, False), (True, True), (False, False)):
+        bn = torch.nn.BatchNorm2d(C).to(DEV)
+        ref = torch.nn.BatchNorm2d(C).double()
+        with torch.no_grad():
+            for m in (bn, ref):
+                m.weight.copy_(T(gm))
+                m.bias.copy_(T(bt))
+                m.running_mean.fill_(0.25)
+                m.running_var.fill_(2.0)
+        xg, rg = G(x).requires_grad_(), G(r).requires_grad_()
+        y = ops.batch_norm_act(xg, bn, relu=relu, residual=rg if use_res else None)
+        (y * G(up)).sum().backward()
+        xc, rc = T(x).double().requires_grad_(), T(r).double().requires_grad_()
+        yc = ref(xc) + (rc if use_res else 0)
+        yc = torch.relu(yc) if relu else yc
+        (yc * T(up).double()).sum().backward()
+        np.testing.assert_allclose(y.detach().cpu().numpy(), yc.detach().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-3, atol=2e-5)
+        if use_res:
+            np.testing.assert_allclose(rg.grad.cpu().numpy(), rc.grad.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref.running_var.numpy(), rtol=1e-5, atol=1e-6)
+        assert int(bn.num_batches_tracked) == 1
+        bn.eval(), ref.eval()
+        with torch.no_grad():
+            ye = ops.batch_norm_act(G(x), bn, relu=relu, residual=G(r) if use_res else None)
+            yr = ref(T(x).double()) + (T(r).double() if use_res else 0)
+            yr = torch.relu(yr) if relu else yr
+        np.testing.assert_allclose(ye.cpu().numpy(), yr.numpy(), rtol=1e-5, atol=1e-5)
