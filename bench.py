@@ -82,6 +82,23 @@ def build_job(args, rank):
     return S, trainer, data_sup, data_unsup, mid
 
 
+# timer key -> kernel symbol in the profiles (template arguments: A layout, B layout, aligned operands)
+KERNEL_SYMBOLS = {"gemm_nt": "gemm_kernel<1, 1, true>", "gemm_nn": "gemm_kernel<1, 0, true>",
+                  "gemm_tn": "gemm_kernel<0, 0, true>", "gemm_tt": "gemm_kernel<0, 1, true>",
+                  "mha_fwd": "mha_fwd_pp_kernel", "mha_bwd": "mha_bwd_kernel<false>"}
+
+
+def measured_traffic(key):
+    """HBM bytes per launch of the kernel class, from the committed counter passes over this same command
+    (profiles/r1_traffic.json, written by tools/collect_traffic.sh); None if no such measurement exists."""
+    symbol = KERNEL_SYMBOLS.get(key.split(" ")[0])
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    if symbol is None or not os.path.exists(path):
+        return None, symbol
+    entry = json.load(open(path))["kernels"].get(symbol)
+    return (round(entry["hbm_bytes_per_launch"]) if entry else None), symbol
+
+
 def cpu_baseline(args):
     """The oracle (a port of the reference's PyTorch-CPU path) on a bounded sample of the same workload."""
     import numpy as np
@@ -188,8 +205,10 @@ def main():
             dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
             a = dom[1]
             ach = a["work"] / (a["ms"] * 1e-3) / 1e12
-            roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            traffic, symbol = measured_traffic(dom[0])
+            roofline = {"kernel": dom[0], "symbol": symbol, "bound": "mfma", "achieved": round(ach, 2),
+                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                        "traffic": traffic,
                         "launches": a["launches"], "avg_us": round(a["ms"] * 1e3 / a["launches"], 2),
                         "flops_per_launch": a["work"] / a["launches"]}
         cpu = None

@@ -15,6 +15,8 @@ from a seed (ops.manual_seed); the random stream differs from torch's, the distr
 """
 import math
 
+import os
+
 import torch
 from torch import nn
 
@@ -64,6 +66,18 @@ class _AttentionParams(nn.Module):
                              p_attn, p_out, self.attn_bf16)
 
 
+# Run the template stream of every fusion layer on a second HIP stream (see _forward_two_streams).
+TWO_STREAMS = os.environ.get("SPOT_TWO_STREAMS", "1") == "1"
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
+
+
 def _ffn(x, l1, l2, p=0.0):
     return ops.FFNFn.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, p)
 
@@ -89,6 +103,8 @@ class FeatureFusionLayer(nn.Module):
 
     def forward(self, src1, src2, kpm1=None, kpm2=None, pos_src1=None, pos_src2=None):
         p = self.dropout if self.training else 0.0      # dropout11..23, dropout1/2 of the reference
+        if TWO_STREAMS and src1.is_cuda:
+            return self._forward_two_streams(src1, src2, kpm1, kpm2, pos_src1, pos_src2, p)
         src1 = self.norm11(self.self_attn1(src1, src1, pos_src1, pos_src1, kpm1, True, True, p))
         src2 = self.norm21(self.self_attn2(src2, src2, pos_src2, pos_src2, kpm2, True, True, p))
         # both cross attentions read the post-ECA streams (:223-230)
@@ -99,6 +115,30 @@ class FeatureFusionLayer(nn.Module):
         src2 = self.norm22(z2)
         src2 = self.norm23(_ffn(src2, self.linear21, self.linear22, p))
         return src1, src2
+
+    def _forward_two_streams(self, src1, src2, kpm1, kpm2, pos_src1, pos_src2, p):
+        """Same computation with the template stream (256 tokens per clip) on a second HIP stream: its kernels
+        are too small to fill the chip and run beside the search stream's (1024 tokens) instead of between
+        them.  The streams meet where cross attention needs the other stream's post-ECA tokens."""
+        main = torch.cuda.current_stream()
+        side = side_stream(src1.device)
+        ops.register_side_stream(side, main)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            src1 = self.norm11(self.self_attn1(src1, src1, pos_src1, pos_src1, kpm1, True, True, p))
+        src2 = self.norm21(self.self_attn2(src2, src2, pos_src2, pos_src2, kpm2, True, True, p))
+        main.wait_stream(side)
+        side.wait_stream(main)
+        src1.record_stream(main)
+        src2.record_stream(side)
+        with torch.cuda.stream(side):
+            z1 = self.multihead_attn1(src1, src2, pos_src1, pos_src2, kpm2, True, False, p)
+            out1 = self.norm13(_ffn(self.norm12(z1), self.linear11, self.linear12, p))
+        z2 = self.multihead_attn2(src2, src1, pos_src2, pos_src1, kpm1, True, False, p)
+        out2 = self.norm23(_ffn(self.norm22(z2), self.linear21, self.linear22, p))
+        main.wait_stream(side)
+        out1.record_stream(main)
+        return out1, out2
 
 
 class DecoderCFALayer(nn.Module):

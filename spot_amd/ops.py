@@ -301,11 +301,41 @@ def _sink(p):
 
 
 def _sink_done(*params):
+    told = False
     for p in params:
         if p is not None:
             s = getattr(p, "_spot_grad_sink", None)
             if s is not None and p.grad is not None:
                 s.grad_ready(p)
+                told = True
+    if told:
+        _join_after_backward()
+
+
+# Side streams (fusion.py runs the template stream of a layer on one).  Autograd only joins the streams of
+# AccumulateGrad nodes with the caller's stream when backward ends; a gradient written into a sink on a side
+# stream has no such node, so the join is queued explicitly, once per backward pass and side stream.
+_SIDE_TO_MAIN = {}
+_JOIN_QUEUED = set()
+
+
+def register_side_stream(side, main):
+    _SIDE_TO_MAIN[side.cuda_stream] = (side, main)
+
+
+def _join_after_backward():
+    cur = torch.cuda.current_stream().cuda_stream
+    pair = _SIDE_TO_MAIN.get(cur)
+    if pair is None or cur in _JOIN_QUEUED:
+        return
+    _JOIN_QUEUED.add(cur)
+    side, main = pair
+
+    def join():
+        _JOIN_QUEUED.discard(cur)
+        main.wait_stream(side)
+
+    torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
 # ---------------------------------------------------------------------------
