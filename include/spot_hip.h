@@ -245,12 +245,26 @@ int spot_groupdw_bwd_f32(const float* x11, const float* x12, const float* x21, c
  * Training forward: batch statistics over (N, HW) per channel; y = [relu]((x - mean) rstd gamma + beta [+ residual]);
  * running_mean / running_var updated with `momentum` (unbiased variance), *num_batches_tracked += 1 (all three may be
  * NULL); save_mean / save_rstd [C] for backward; relu_sign [N*C*HW/4] bytes (bit j = element j of the float4 passed
- * the ReLU; NULL when no gradient is needed).  ws: spot_batchnorm_ws_floats(N, C) floats. */
+ * the ReLU; NULL when no gradient is needed).  deferred_stats [2C] (may be NULL): receives the batch mean and the
+ * unbiased batch variance for a later spot_batchnorm_apply_deferred (pass the running buffers as NULL then).
+ * ws: spot_batchnorm_ws_floats(N, C) floats. */
 long spot_batchnorm_ws_floats(int N, int C);
 int spot_batchnorm_fwd_train_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, long long* num_batches_tracked, float* y,
-                                 float* save_mean, float* save_rstd, unsigned char* relu_sign, float* ws, int N,
-                                 int C, int HW, float eps, float momentum, int relu, hipStream_t stream);
+                                 float* save_mean, float* save_rstd, unsigned char* relu_sign, float* deferred_stats,
+                                 float* ws, int N, int C, int HW, float eps, float momentum, int relu,
+                                 hipStream_t stream);
+/* One pending running-statistics update: running = (1 - momentum) running + momentum stats, tracked += 1. */
+typedef struct spot_bn_deferred {
+    float* running_mean;              /* [C] */
+    float* running_var;               /* [C] */
+    long long* num_batches_tracked;   /* may be NULL */
+    const float* stats;               /* [2C]: batch mean, unbiased batch variance (deferred_stats of the forward) */
+    int C;
+    float momentum;
+} spot_bn_deferred;
+/* Applies n pending updates (table in device memory), in table order, in one launch. */
+int spot_batchnorm_apply_deferred(const spot_bn_deferred* table_dev, int n, hipStream_t stream);
 /* Inference forward with the running statistics (one pass). */
 int spot_batchnorm_fwd_infer_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                                  const float* running_mean, const float* running_var, float* y, int N, int C,

@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        float* __restrict__ run_mean, float* __restrict__ run_var,
                                                        long long* __restrict__ tracked, float* __restrict__ y,
                                                        float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                                                       unsigned char* __restrict__ sign, int N, int C, int HW4, int S,
-                                                       float eps, float momentum) {
+                                                       unsigned char* __restrict__ sign, float* __restrict__ deferred,
+                                                       int N, int C, int HW4, int S, float eps, float momentum) {
     __shared__ float red[4];
     const int c = blockIdx.x, s = blockIdx.y;
     float s1, s2;
@@ -108,6 +108,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             run_var[c] = (1.f - momentum) * run_var[c] + momentum * (var * (M / (M - 1.f)));
         }
         if (tracked && c == 0) *tracked += 1;
+        if (deferred) {
+            deferred[c] = mean;
+            deferred[C + c] = var * (M / (M - 1.f));
+        }
     }
     const float a = rstd * gamma[c], b = beta[c] - mean * a;
     const Slice sl = slice_of(N, S, s);
@@ -229,8 +233,8 @@ extern "C" long spot_batchnorm_ws_floats(int N, int C) { return (long)C * split_
 extern "C" int spot_batchnorm_fwd_train_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                                             float* running_mean, float* running_var, long long* num_batches_tracked,
                                             float* y, float* save_mean, float* save_rstd, unsigned char* relu_sign,
-                                            float* ws, int N, int C, int HW, float eps, float momentum, int relu,
-                                            hipStream_t stream) {
+                                            float* deferred_stats, float* ws, int N, int C, int HW, float eps,
+                                            float momentum, int relu, hipStream_t stream) {
     SPOT_CHECK_ARG(shape_ok(N, C, HW), "batchnorm_fwd_train: bad shape N=%d C=%d HW=%d (HW must be a multiple of 4)", N, C, HW);
     SPOT_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd && ws, "batchnorm_fwd_train: null pointer");
     SPOT_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "batchnorm_fwd_train: running stats come in pairs");
@@ -242,8 +246,8 @@ extern "C" int spot_batchnorm_fwd_train_f32(const float* x, const float* residua
     SPOT_CHECK_LAUNCH("batchnorm_fwd_train(stats)");
 #define SPOT_BN_APPLY(R, A)                                                                                             \
     bn_apply_kernel<R, A><<<grid, 256, 0, stream>>>(x, residual, ws, gamma, beta, running_mean, running_var,             \
-                                                    num_batches_tracked, y, save_mean, save_rstd, relu_sign, N, C, HW / 4, \
-                                                    S, eps, momentum)
+                                                    num_batches_tracked, y, save_mean, save_rstd, relu_sign,            \
+                                                    deferred_stats, N, C, HW / 4, S, eps, momentum)
     if (relu && residual) SPOT_BN_APPLY(true, true);
     else if (relu) SPOT_BN_APPLY(true, false);
     else if (residual) SPOT_BN_APPLY(false, true);
@@ -287,5 +291,28 @@ extern "C" int spot_batchnorm_bwd_f32(const float* dy, const float* x, const uns
     bn_bwd_apply_kernel<<<grid, 256, 0, stream>>>(dy, x, relu_sign, save_mean, save_rstd, gamma, ws, dx, d_residual, dgamma,
                                                   dbeta, N, C, HW / 4, S, accumulate);
     SPOT_CHECK_LAUNCH("batchnorm_bwd(apply)");
+    return SPOT_OK;
+}
+
+// Running-statistics updates that a forward pass left pending (deferred_stats of the training forward): one
+// launch applies them for a whole network, in table order.  Used when two forward passes through the same
+// BatchNorm layers run concurrently on two streams: the second pass in program order defers its update so the
+// result equals the sequential one.
+namespace {
+__global__ __launch_bounds__(256) void bn_deferred_kernel(const spot_bn_deferred* __restrict__ table, int n) {
+    const spot_bn_deferred e = table[blockIdx.x];
+    for (int c = threadIdx.x; c < e.C; c += 256) {
+        e.running_mean[c] = (1.f - e.momentum) * e.running_mean[c] + e.momentum * e.stats[c];
+        e.running_var[c] = (1.f - e.momentum) * e.running_var[c] + e.momentum * e.stats[e.C + c];
+    }
+    if (threadIdx.x == 0 && e.num_batches_tracked) *e.num_batches_tracked += 1;
+}
+}  // namespace
+
+extern "C" int spot_batchnorm_apply_deferred(const spot_bn_deferred* table_dev, int n, hipStream_t stream) {
+    SPOT_CHECK_ARG(n >= 0 && (n == 0 || table_dev), "batchnorm_apply_deferred: bad arguments");
+    if (n == 0) return SPOT_OK;
+    bn_deferred_kernel<<<n, 256, 0, stream>>>(table_dev, n);
+    SPOT_CHECK_LAUNCH("batchnorm_apply_deferred");
     return SPOT_OK;
 }

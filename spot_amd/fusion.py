@@ -69,6 +69,9 @@ class _AttentionParams(nn.Module):
 # Run the template stream of every fusion layer on a second HIP stream (see _forward_two_streams).
 TWO_STREAMS = os.environ.get("SPOT_TWO_STREAMS", "1") == "1"
 _SIDE_STREAMS = {}
+if TWO_STREAMS and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    # parameters of the template stream receive their gradients on the second stream by design
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
 
 def side_stream(device):

@@ -55,7 +55,8 @@ SIGNATURES = {
     "spot_groupdw_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "spot_xcorr_depthwise_bwd_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "spot_groupdw_bwd_f32": [vp] * 15 + [i32, i32, i32, i32, i32, vp],
-    "spot_batchnorm_fwd_train_f32": [vp] * 12 + [i32, i32, i32, f32, f32, i32, vp],
+    "spot_batchnorm_fwd_train_f32": [vp] * 13 + [i32, i32, i32, f32, f32, i32, vp],
+    "spot_batchnorm_apply_deferred": [vp, i32, vp],
     "spot_batchnorm_fwd_infer_f32": [vp] * 7 + [i32, i32, i32, f32, i32, vp],
     "spot_batchnorm_bwd_f32": [vp] * 11 + [i32, i32, i32, i32, vp],
     "spot_gemm_f32": [C.POINTER(GemmDesc), vp],

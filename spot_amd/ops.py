@@ -574,7 +574,8 @@ class BatchNormActFn(torch.autograd.Function):
     """y = [relu](batch_norm(x) [+ residual]) in training mode (batch statistics, running stats updated)."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, tracked, eps, momentum, relu):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, tracked, eps, momentum, relu,
+                deferred=None):
         x = _chk(x.contiguous())
         N, Cn, H, W = x.shape
         HW = H * W
@@ -588,8 +589,8 @@ class BatchNormActFn(torch.autograd.Function):
         sign = torch.empty((x.numel() // 4,), dtype=torch.uint8, device=dev) if (relu and need) else None
         ws = torch.empty((lib.load().spot_batchnorm_ws_floats(N, Cn),), dtype=torch.float32, device=dev)
         lib.call("spot_batchnorm_fwd_train_f32", _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean),
-                 _p(running_var), _p(tracked), _p(y), _p(mean), _p(rstd), _p(sign), _p(ws), N, Cn, HW, float(eps),
-                 float(momentum), int(relu), _st())
+                 _p(running_var), _p(tracked), _p(y), _p(mean), _p(rstd), _p(sign), _p(deferred), _p(ws), N, Cn, HW,
+                 float(eps), float(momentum), int(relu), _st())
         if need:
             ctx.save_for_backward(x, sign, mean, rstd, gamma)
             ctx.params = (gamma, beta)
@@ -614,7 +615,57 @@ class BatchNormActFn(torch.autograd.Function):
         if direct:
             _sink_done(pg, pb)
             dg = db = None
-        return dx, dres, dg, db, None, None, None, None, None, None
+        return dx, dres, dg, db, None, None, None, None, None, None, None
+
+
+class _BnDeferred(C.Structure):
+    _fields_ = [("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+                ("stats", C.c_void_p), ("C", C.c_int), ("momentum", C.c_float)]
+
+
+class defer_running_stats:
+    """Context in which training-mode batch_norm_act leaves the running-statistics update pending.
+
+    For a forward pass that runs on a second stream beside another pass through the same BatchNorm layers:
+    both would read-modify-write the running buffers.  The deferred pass stores its batch statistics in a
+    per-layer buffer instead; ``apply()`` (on the main stream, after the streams have joined) performs all
+    pending updates in one launch, so the buffers end up as if the passes had run one after the other."""
+    _active = None
+    _tables = {}
+
+    def __enter__(self):
+        self.layers = []
+        self._prev = defer_running_stats._active
+        defer_running_stats._active = self
+        return self
+
+    def __exit__(self, *exc):
+        defer_running_stats._active = self._prev
+        return False
+
+    def buffer_for(self, bn):
+        buf = getattr(bn, "_spot_deferred_stats", None)
+        if buf is None or buf.device != bn.weight.device:
+            buf = torch.empty((2 * bn.num_features,), dtype=torch.float32, device=bn.weight.device)
+            bn._spot_deferred_stats = buf
+        self.layers.append(bn)
+        return buf
+
+    def apply(self):
+        if not self.layers:
+            return
+        key = tuple((id(bn), bn.running_mean.data_ptr(), bn._spot_deferred_stats.data_ptr()) for bn in self.layers)
+        table = defer_running_stats._tables.get(key)
+        if table is None:
+            arr = (_BnDeferred * len(self.layers))()
+            for e, bn in zip(arr, self.layers):
+                e.running_mean, e.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                e.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+                e.stats, e.C, e.momentum = bn._spot_deferred_stats.data_ptr(), bn.num_features, bn.momentum
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            table = host.to(self.layers[0].weight.device)
+            defer_running_stats._tables[key] = table
+        lib.call("spot_batchnorm_apply_deferred", _p(table), len(self.layers), _st())
 
 
 def batch_norm_act(x, bn, relu=False, residual=None):
@@ -626,6 +677,10 @@ def batch_norm_act(x, bn, relu=False, residual=None):
         if bn.momentum is None:
             raise RuntimeError("spot_amd: cumulative-average BatchNorm (momentum=None) is not supported")
         track = bn.track_running_stats
+        pending = defer_running_stats._active
+        if track and pending is not None:
+            return BatchNormActFn.apply(x, residual, bn.weight, bn.bias, None, None, None, bn.eps, bn.momentum, relu,
+                                        pending.buffer_for(bn))
         return BatchNormActFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean if track else None,
                                     bn.running_var if track else None, bn.num_batches_tracked if track else None,
                                     bn.eps, bn.momentum, relu)

@@ -144,6 +144,26 @@ class TransT(nn.Module):
         pos = self.backbone[1].rows(feat.shape[2], feat.shape[3], feat.device)
         return tok, pos
 
+    def _features_pair(self, search, template):
+        """Search and template feature extraction (the reference runs them back to back, search first).  On a
+        GPU the template pass, whose 16x16..64x64 maps cannot fill the chip, runs on a second stream beside the
+        search pass; its BatchNorm running-statistics updates are applied afterwards so the buffers end up as
+        in the sequential order."""
+        from . import fusion
+        if not (fusion.TWO_STREAMS and search.is_cuda):
+            return self._features(search), self._features(template)
+        main = torch.cuda.current_stream()
+        side = fusion.side_stream(search.device)
+        ops.register_side_stream(side, main)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), ops.defer_running_stats() as pending:
+            out_t = self._features(template)
+        out_s = self._features(search)
+        main.wait_stream(side)
+        out_t[0].record_stream(main)
+        pending.apply()
+        return out_s, out_t
+
     def _heads(self, hs, use_iou=False, b_iou=0):
         out = {"pred_logits": self.class_embed(hs), "pred_boxes": self.bbox_embed(hs).sigmoid()}
         if self.iou_embed is not None and use_iou:
@@ -195,8 +215,7 @@ class TransT(nn.Module):
         template = (templates[0] if len(templates) == 1 else torch.cat(templates, dim=0)).detach()
         search = (searches[0] if len(searches) == 1 else torch.cat(searches, dim=0)).detach()
 
-        src_search, pos_search = self._features(search)
-        src_template, pos_template = self._features(template)
+        (src_search, pos_search), (src_template, pos_template) = self._features_pair(search, template)
         hs = self.featurefusion_network.forward_tokens(src_template, src_search, pos_template, pos_search)
 
         if teacher_data is not None:

@@ -134,6 +134,39 @@ def test_student_step_golden(golden):
                                    atol=2e-3 * max(1e-6, float(np.abs(ref).max())), err_msg=k)
 
 
+def test_two_stream_forward_matches_sequential_including_running_stats():
+    """Template pass on a second stream with deferred BatchNorm running-stat updates == the sequential order."""
+    from spot_amd import fusion
+    from spot_amd.tensordict import TensorDict
+    from tests.test_oracle_model import student_batches
+    outs = []
+    saved = fusion.TWO_STREAMS
+    try:
+        for two in (False, True):
+            fusion.TWO_STREAMS = two
+            net = build(13, dropout=0.0).train()
+            sup, sp = student_batches(13, 2, 2)
+            sup = TensorDict({k: v.to(DEV) for k, v in sup.items()})
+            sp = TensorDict({k: v.to(DEV) for k, v in sp.items()})
+            with torch.no_grad():
+                for _ in range(2):      # two iterations: the second starts from updated running buffers
+                    out = net(burnin_data=TensorDict(sup), sp_data=TensorDict(sp))
+            torch.cuda.synchronize()
+            outs.append((out, {k: v.detach().clone() for k, v in net.state_dict().items() if "running" in k or
+                               "tracked" in k}))
+    finally:
+        fusion.TWO_STREAMS = saved
+    (o0, s0), (o1, s1) = outs
+    for k in s0:
+        if "tracked" in k:
+            assert torch.equal(s0[k], s1[k]), k
+        else:       # the convolution library may pick another algorithm on the second stream: rounding-level spread
+            np.testing.assert_allclose(s0[k].cpu().numpy(), s1[k].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+    assert int(s1["backbone.0.body.bn1.num_batches_tracked"]) == 4      # search + template, twice
+    for k in ("logits_sup", "boxes_unsup"):
+        np.testing.assert_allclose(o0[k].cpu().numpy(), o1[k].cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_student_step_bf16_attention_tracks_fp32(golden):
     """Training configuration with bf16 attention products (fp32 softmax/accumulate, fp32 elsewhere): loss within
     1e-2 relative of the reference's fp32 loss, gradients within cosine 0.999 of the fp32 run's."""
