@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1, help="student dropout (reference config: 0.1)")
     ap.add_argument("--attention", choices=("f32", "bf16"), default="f32",
                     help="attention-core matrix products: exact fp32 (default, the headline config) or bf16")
+    ap.add_argument("--exclusive-steps", type=int, default=2,
+                    help="extra untimed-for-throughput steps with the second stream off, for per-kernel durations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -188,6 +190,22 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     ops.TIMER = None
+    # The fusion layers and the backbone run the template stream on a second HIP stream, so in the timed region a
+    # launch's duration includes the kernels that share the chip with it.  A short extra leg with the second
+    # stream switched off gives each kernel's duration when it has the chip to itself (reported beside the
+    # timed region's figure, never instead of it).
+    exclusive = None
+    if timer is not None and args.exclusive_steps > 0:
+        from spot_amd import fusion
+        two = fusion.TWO_STREAMS
+        fusion.TWO_STREAMS = False
+        step(args.warmup + args.steps)          # settle into the serial schedule
+        exclusive = ops.TIMER = ops.KernelTimer()
+        for i in range(args.exclusive_steps):
+            step(args.warmup + args.steps + 1 + i)
+        torch.cuda.synchronize()
+        ops.TIMER = None
+        fusion.TWO_STREAMS = two
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,6 +229,15 @@ def main():
                         "traffic": traffic,
                         "launches": a["launches"], "avg_us": round(a["ms"] * 1e3 / a["launches"], 2),
                         "flops_per_launch": a["work"] / a["launches"]}
+            if exclusive is not None:
+                x = exclusive.summary().get(dom[0])
+                if x and x["ms"] > 0:
+                    xa = x["work"] / (x["ms"] * 1e-3) / 1e12
+                    roofline["second_stream_off"] = {
+                        "achieved": round(xa, 2), "frac": round(xa / PEAK_F32_MFMA_TFLOPS, 4),
+                        "avg_us": round(x["ms"] * 1e3 / x["launches"], 2), "launches": x["launches"],
+                        "note": "same kernels in %d extra steps with the template stream serialised behind the "
+                                "search stream: a launch then has the chip to itself" % args.exclusive_steps}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args)

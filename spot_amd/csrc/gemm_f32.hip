@@ -20,6 +20,7 @@
 // operands, which is a pure re-ordering of the k sum.
 #include "common.h"
 #include "../../include/spot_hip.h"
+#include <type_traits>
 
 namespace {
 
@@ -46,6 +47,7 @@ struct GemmArgs {
     const float* mask; long ldmask;   // multiply by (mask[m][n] > 0)
     const float* residual; long ldres; long strideRes;
     int cvec;                         // every epilogue operand allows 16-byte accesses
+    int fast;                         // operands allow the unguarded interior-tile loader (see gemm_kernel)
     unsigned drop_thr, drop_seed; float drop_scale;   // dropout after relu, before residual (0 = off)
 };
 
@@ -147,44 +149,78 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
         load_tile<LA, ALIGNED>(A + seg * g.segA, g.lda, m0, kin, g.M, min(g.kseg, g.K - seg * g.kseg), sa, tid);
         load_tile<LB, ALIGNED>(B + seg * g.segB, g.ldb, n0, kin, g.N, min(g.kseg, g.K - seg * g.kseg), sb, tid);
     };
+    // Interior tiles (whole 128x128 tile and every k tile in bounds, 16-byte aligned operands): the guarded
+    // loader above costs a chain of ~90 branchy basic blocks per k tile; here a thread keeps four 32-bit
+    // element offsets per operand and the k walk is one scalar base-pointer bump per tile.
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        offA[i] = LA ? (unsigned)((m0 + (f >> 3)) * g.lda + ((f & 7) << 2)) : (unsigned)((f >> 5) * g.lda + m0 + ((f & 31) << 2));
+        offB[i] = LB ? (unsigned)((n0 + (f >> 3)) * g.ldb + ((f & 7) << 2)) : (unsigned)((f >> 5) * g.ldb + n0 + ((f & 31) << 2));
+    }
+    int fseg = (kt0 * BK) / g.kseg, fkin = kt0 * BK - fseg * g.kseg;     // position of the next tile to fetch
+    auto fetch_fast = [&]() {
+        const float* Ab = A + fseg * g.segA + (LA ? (long)fkin : (long)fkin * g.lda);
+        const float* Bb = B + fseg * g.segB + (LB ? (long)fkin : (long)fkin * g.ldb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sa[i] = *reinterpret_cast<const float4*>(Ab + offA[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sb[i] = *reinterpret_cast<const float4*>(Bb + offB[i]);
+        fkin += BK;
+        if (fkin >= g.kseg) {
+            fkin = 0;
+            ++fseg;
+        }
+    };
+    const bool fast = ALIGNED && g.fast && m0 + BM <= g.M && n0 + BN <= g.N;
 
     // One LDS buffer per operand (36.9 KB per workgroup, so three workgroups share a CU and the
     // prologue / epilogue of one hides behind the matrix work of the others).  The next tile's
     // global loads are in flight during the 64 MFMAs of the current tile and land in LDS between
     // two barriers.
-    if (kt0 < kt1) {
-        fetch(kt0);
-        store_tile<LA>(As, sa, tid);
-        store_tile<LB>(Bs, sb, tid);
-    }
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const bool more = kt + 1 < kt1;
-        if (more) fetch(kt + 1);
-#pragma unroll
-        for (int gk = 0; gk < BK / 8; ++gk) {
-            float4 a[2], b[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) a[t] = read_frag<LA>(As, wm * 64 + t * 32 + l31, gk, h);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) b[u] = read_frag<LB>(Bs, wn * 64 + u * 32 + l31, gk, h);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-        if (more) {
+    auto k_loop = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        if (kt0 < kt1) {
+            if (FAST) fetch_fast();
+            else fetch(kt0);
             store_tile<LA>(As, sa, tid);
             store_tile<LB>(Bs, sb, tid);
-            __syncthreads();
         }
-    }
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const bool more = kt + 1 < kt1;
+            if (more) {
+                if (FAST) fetch_fast();
+                else fetch(kt + 1);
+            }
+#pragma unroll
+            for (int gk = 0; gk < BK / 8; ++gk) {
+                float4 a[2], b[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) a[t] = read_frag<LA>(As, wm * 64 + t * 32 + l31, gk, h);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) b[u] = read_frag<LB>(Bs, wn * 64 + u * 32 + l31, gk, h);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+            if (more) {
+                store_tile<LA>(As, sa, tid);
+                store_tile<LB>(Bs, sb, tid);
+                __syncthreads();
+            }
+        }
+    };
+    if (fast) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 
     // epilogue.  Per-lane dword stores of the accumulator layout (32 floats per row segment) are
     // store-issue bound, so the tile is transposed through LDS (free after the k loop) and leaves
@@ -350,6 +386,10 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
              (!a.bias || al(a.bias)) && (!a.rowbias || (al(a.rowbias) && a.ldrb % 4 == 0)) &&
              (!a.mask || (al(a.mask) && a.ldmask % 4 == 0)) &&
              (!a.residual || (al(a.residual) && a.ldres % 4 == 0 && a.strideRes % 4 == 0));
+    // interior-tile loader: every k tile whole and inside one segment, element offsets within 32 bits
+    const long extA = ta ? (long)a.M * a.lda : (long)a.kseg * a.lda + a.M;
+    const long extB = tb ? (long)a.N * a.ldb : (long)a.kseg * a.ldb + a.N;
+    a.fast = aligned && a.K % BK == 0 && a.kseg % BK == 0 && extA < (1L << 31) && extB < (1L << 31);
     if (ta && tb) launch<1, 1>(a, d->batch, aligned, stream);
     else if (ta && !tb) launch<1, 0>(a, d->batch, aligned, stream);
     else if (!ta && tb) launch<0, 1>(a, d->batch, aligned, stream);

@@ -456,15 +456,15 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const unsigned char* __restrict__ kpm, float* __restrict__ dQ, long lddq, float* __restrict__ dK, long lddk,
     float* __restrict__ dV, long lddv, int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed,
     float drop_scale) {
-    // LDS: 2 x (Q tile, dO tile) [32][QP], 2 x (lse, delta) [32], K tile [128][QP], 4 x dS [32][QP]
-    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * QP + 4 * 32 + 128 * QP + 4 * 32 * QP];
+    // LDS: 2 x (Q tile, dO tile) [32][QP], 2 x (lse, delta) [32], K tile [128][QP], 2 x 4 x dS/dQ patch [32][QP]
+    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * QP + 4 * 32 + 128 * QP + 2 * 4 * 32 * QP];
     auto Qs = [&](int buf) { return lds + buf * 32 * QP; };
     auto Gs = [&](int buf) { return lds + (2 + buf) * 32 * QP; };
     auto Ls = [&](int buf) { return lds + 4 * 32 * QP + buf * 64; };
     auto Ds = [&](int buf) { return lds + 4 * 32 * QP + buf * 64 + 32; };
     float* Kt = lds + 4 * 32 * QP + 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
-    float* dSs = Kt + 128 * QP + wave * 32 * QP;
+    float* const patches = Kt + 128 * QP;       // [2 sets][4 waves][32][QP]
 
     const int head = blockIdx.y, b = blockIdx.z;
     const int key_w0 = blockIdx.x * 128 + wave * 32;
@@ -532,6 +532,10 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     }
     __syncthreads();
     const bool any_dead = __builtin_amdgcn_ballot_w64(kdead) != 0;
+    // B operand of dQ = dS K: rows 16h .. 16h+15 of this wave's (scaled) keys, fixed for the whole sweep
+    Frag<BF16> kq;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) kq.set(j, Kt[(wave * 32 + 16 * h + j) * QP + l31]);
     f32x16 dk, dv;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
@@ -595,7 +599,10 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
             load_frag_rows(qf, qs, QP, h, l31);
             mma(df, qf, dk);
         }
-        // ---- dQ tile = dS K : transpose dS through this wave's LDS patch
+        // ---- dQ tile = dS K : transpose dS through this wave's LDS patch (patch sets alternate per tile, so a
+        //      wave that runs ahead never overwrites a patch the others still reduce from)
+        float* const pset = patches + (t & 1) * 4 * 32 * QP;
+        float* const dSs = pset + wave * 32 * QP;
 #pragma unroll
         for (int e = 0; e < 16; ++e) dSs[acc_row(e, h) * QP + l31] = dp[e];
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
@@ -604,19 +611,28 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[e] = 0.f;
         {
-            Frag<BF16> af, bf;
+            Frag<BF16> af;
             load_frag(af, dSs + l31 * QP + 16 * h);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) bf.set(j, Kt[(wave * 32 + 16 * h + j) * QP + l31]);
-            mma(af, bf, dq);
+            mma(af, kq, dq);
         }
+        // The four waves hold partial dQ tiles over their 32 keys each.  Float atomics are served at the memory
+        // side at a fixed rate, so the partials are summed through the (now free) patches first: one atomic per
+        // element per workgroup instead of four.
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int qr = t * 32 + acc_row(e, h);
-            if (qr < Lq) atomicAdd(dQ + ((long)b * Lq + qr) * lddq + head * DH + l31, dq[e]);
-        }
+        for (int e = 0; e < 16; ++e) dSs[acc_row(e, h) * QP + l31] = dq[e];
         if (more) stash(cur ^ 1);
         __syncthreads();
+        {
+            const int col = tid & 31;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (tid >> 5) + 8 * i;
+                const float* pp = pset + row * QP + col;
+                const float v = (pp[0] + pp[32 * QP]) + (pp[2 * 32 * QP] + pp[3 * 32 * QP]);
+                const int qr = t * 32 + row;
+                if (qr < Lq) atomicAdd(dQ + ((long)b * Lq + qr) * lddq + head * DH + col, v);
+            }
+        }
     }
     // dK / dV: rows = this wave's keys, cols = channel on the lanes
 #pragma unroll

@@ -7,6 +7,7 @@ transt.py) read like the reference's nn.Modules.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -416,9 +417,12 @@ def linear_dgrad(dy2, W, mask=None, out=None, accumulate=False, residual=None, a
     return out
 
 
+_SPLITK_TARGET = int(os.environ.get("SPOT_SPLITK_TARGET", "512"))
+
+
 def _splitk_for(rows_out, cols_out, k):
     tiles = ((rows_out + 127) // 128) * ((cols_out + 127) // 128)
-    want = max(1, 512 // tiles)
+    want = max(1, _SPLITK_TARGET // tiles)
     return max(1, min(want, k // 256 if k >= 256 else 1))
 
 
