@@ -174,8 +174,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # every step hands the trainer the next step's unlabelled batch too (here the same resident batch), as a
+    # data loader with one batch of look-ahead would
+    unsup_view = TensorDict(data_unsup)
+    prefetch = os.environ.get("SPOT_PREFETCH_TEACHER", "1") == "1"
+
     def step(i):
-        return trainer.train_iteration(i, TensorDict(data_sup), TensorDict(data_unsup), mid)
+        return trainer.train_iteration(i, TensorDict(data_sup), unsup_view, mid,
+                                       next_unsup=unsup_view if prefetch else None)
 
     for i in range(args.warmup):
         step(i)

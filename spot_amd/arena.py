@@ -37,6 +37,7 @@ class ParamArena:
             t.data = self.flat_i64[j]
         self.grad_flat = None
         self._ready_listeners = []
+        self._owed = {}
         if with_grads:
             self.attach_grads()
 
@@ -53,14 +54,27 @@ class ParamArena:
     def add_ready_listener(self, fn):
         self._ready_listeners.append(fn)
 
+    def expect(self, p):
+        """Forward of an op that will add p's gradient into p.grad itself: one more contribution is owed."""
+        self._owed[id(p)] = self._owed.get(id(p), 0) + 1
+
     def grad_ready(self, p):
-        """A kernel finished enqueueing p's gradient into p.grad (the autograd hook does not fire for it)."""
+        """A kernel finished enqueueing one contribution to p.grad (the autograd hook does not fire for it).
+        Listeners hear about p once, when every op that used p in the forward pass has delivered (a parameter
+        can serve several ops: both backbone passes share their BatchNorm layers, input_proj runs twice)."""
+        left = self._owed.get(id(p), 1) - 1
+        self._owed[id(p)] = left
+        if left > 0:
+            return
         for fn in self._ready_listeners:
             fn(p)
 
     def zero_grad(self):
+        """Clear the flat gradient buffer.  Call it BEFORE the forward pass of a step: it also forgets which
+        kernels still owe a gradient (see expect / grad_ready)."""
         if self.grad_flat is not None:
             self.grad_flat.zero_()
+        self._owed.clear()
 
     def signature(self):
         return [(k, tuple(t.shape)) for k, t in self.f32], [k for k, _ in self.i64]

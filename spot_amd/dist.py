@@ -74,6 +74,7 @@ class GradBucketReducer:
             self.buckets.append([cur_lo, cur_hi, count])
         self.pending = [0] * len(self.buckets)
         self.handles = []
+        self._seen = set()
         self._armed = False
         if self.world > 1:
             for k, t, o in params:
@@ -84,11 +85,15 @@ class GradBucketReducer:
         """Call before backward of each step."""
         self.pending = [b[2] for b in self.buckets]
         self.handles = []
+        self._seen = set()
         self._armed = True
 
     def _hook(self, p):
-        if not self._armed:
+        # A parameter can be announced twice (by the kernel that wrote its gradient into the buffer and by
+        # autograd's own accumulation node); it counts once.
+        if not self._armed or id(p) in self._seen:
             return
+        self._seen.add(id(p))
         b = self.param_bucket[id(p)]
         self.pending[b] -= 1
         if self.pending[b] == 0:
@@ -96,6 +101,17 @@ class GradBucketReducer:
 
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
+        if self.arena.grad_flat.is_cuda:
+            # The bucket's gradients were written by kernels on the main stream AND on the second stream the
+            # fusion layers / backbone use for the template branch; the collective only orders itself behind
+            # the stream it is issued from, so that stream first waits for every stream that produced them.
+            from . import ops
+            cur = torch.cuda.current_stream()
+            for side, main in ops.compute_streams():
+                if side.cuda_stream != cur.cuda_stream:
+                    cur.wait_stream(side)
+                if main.cuda_stream != cur.cuda_stream:
+                    cur.wait_stream(main)
         self.handles.append(dist.all_reduce(self.arena.grad_flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         self.pending[b] = -1
 

@@ -75,9 +75,12 @@ if TWO_STREAMS and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_st
 
 
 def side_stream(device):
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    """The second stream that belongs to the current stream (one per (device, current stream) pair, so passes
+    issued from different streams do not share a side stream)."""
+    dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _SIDE_STREAMS[key]
 
 

@@ -301,6 +301,15 @@ def _sink(p):
     return p.grad
 
 
+def _sink_expect(*params):
+    """Forward-side twin of _sink_done: the op being recorded will deliver these parameters' gradients itself."""
+    for p in params:
+        if p is not None and p.requires_grad:
+            s = getattr(p, "_spot_grad_sink", None)
+            if s is not None and p.grad is not None:
+                s.expect(p)
+
+
 def _sink_done(*params):
     told = False
     for p in params:
@@ -322,6 +331,11 @@ _JOIN_QUEUED = set()
 
 def register_side_stream(side, main):
     _SIDE_TO_MAIN[side.cuda_stream] = (side, main)
+
+
+def compute_streams():
+    """(side, main) stream pairs the network passes have used so far."""
+    return list(_SIDE_TO_MAIN.values())
 
 
 def _join_after_backward():
@@ -458,6 +472,7 @@ class LinearFn(torch.autograd.Function):
         ctx.relu = relu
         ctx.save_for_backward(x2, W, y if relu else None)
         ctx.params = (W, b)
+        _sink_expect(W if ctx.needs_input_grad[1] else None, b if ctx.needs_input_grad[2] else None)
         return y.view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
@@ -502,6 +517,7 @@ class FFNFn(torch.autograd.Function):
         ctx.save_for_backward(x2, h, W1, W2)
         ctx.drop = (p, s2)
         ctx.params = (W1, b1, W2, b2)
+        _sink_expect(*ctx.params)
         return z.view_as(x)
 
     @staticmethod
@@ -537,6 +553,8 @@ class LayerNormFn(torch.autograd.Function):
                  float(eps), _st())
         ctx.save_for_backward(x2, mean, rstd, gamma)
         ctx.params = (gamma, beta)
+        if _sink(gamma) is not None and _sink(beta) is not None:
+            _sink_expect(gamma, beta)
         return y.view_as(x)
 
     @staticmethod
@@ -599,6 +617,8 @@ class BatchNormActFn(torch.autograd.Function):
             ctx.save_for_backward(x, sign, mean, rstd, gamma)
             ctx.params = (gamma, beta)
             ctx.has_res = residual is not None
+            if _sink(gamma) is not None and _sink(beta) is not None:
+                _sink_expect(gamma, beta)
         return y
 
     @staticmethod
@@ -782,6 +802,7 @@ class MHAFn(torch.autograd.Function):
             ctx.drop = (p_attn, sa, p_out, so)
             ctx.bwd_entry = "spot_mha_bwd_bf16" if bf16 else "spot_mha_bwd_f32"
             ctx.params = (in_w, in_b, out_w, out_b)
+            _sink_expect(*ctx.params)
         return z.view(B, Lq, Cn)
 
     @staticmethod

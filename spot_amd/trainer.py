@@ -45,6 +45,8 @@ class LTRSparseTrainer:
         self.reducer = GradBucketReducer(self.arena)
         self.num_frames = 0
         self.skipped = 0
+        self._prefetched = None
+        self._teacher_stream = None
 
     # -- one epoch over the two loaders ----------------------------------------
     def cycle_dataset_sparse_supervised(self, loader_sup, loader_unsup, training=True):
@@ -54,14 +56,22 @@ class LTRSparseTrainer:
             last = self.train_iteration(i, data_sup, data_unsup, middle_info, training)
         return last
 
-    def train_iteration(self, i, data_sup, data_unsup, middle_info, training=True):
+    def train_iteration(self, i, data_sup, data_unsup, middle_info, training=True, next_unsup=None):
+        """One iteration of the hot loop.  ``next_unsup`` (optional): the unlabelled batch of iteration i+1.  When
+        no teacher update falls between the two iterations, its pseudo labels are computed on a separate stream
+        while this iteration's student backward runs: the teacher's weights are the same either way, so the
+        labels are the ones iteration i+1 would compute itself."""
         if (i + 1) % self.settings.teacher_update_frequency == 0:
             self._teacher_model_update(keep_rate=self.settings.keep_rate)
         if self.move_data_to_gpu:
             data_unsup = data_unsup.to(self.device, non_blocking=True)
             data_sup = data_sup.to(self.device, non_blocking=True)
-        pseudo_label = self._pseudo_label_generation(data_unsup)
+        pseudo_label = self._take_prefetched(i, data_unsup)
+        if pseudo_label is None:
+            pseudo_label = self._pseudo_label_generation(data_unsup)
         aug_label = self._middleware_ops(middle_info, pseudo_label)
+        if training:
+            self.arena.zero_grad()      # before the forward pass: also resets the kernels' gradient bookkeeping
         loss, stats, n_keep = self._sparse_training(data_sup, data_unsup, aug_label, training)
         # single host read: kept count and loss finiteness
         flags = torch.stack([n_keep.float().reshape(()), torch.isfinite(loss.detach()).float().reshape(())]).tolist()
@@ -70,13 +80,43 @@ class LTRSparseTrainer:
             self.skipped += 1
             return None
         if training:
-            self.arena.zero_grad()
             self.reducer.arm()
+            self._prefetch_pseudo_labels(i + 1, next_unsup)
             loss.backward()
             self.reducer.finish()
             self.optimizer.step()
         self.num_frames += self.settings.batch_size
         return stats
+
+    # -- teacher pass of the next iteration beside this iteration's backward ----------
+    def _prefetch_pseudo_labels(self, i_next, next_unsup):
+        self._prefetched = None
+        if next_unsup is None or self.device.type != "cuda":
+            return
+        if (i_next + 1) % self.settings.teacher_update_frequency == 0:
+            return                              # the teacher changes before iteration i_next: nothing to reuse
+        main = torch.cuda.current_stream()
+        if self._teacher_stream is None:
+            self._teacher_stream = torch.cuda.Stream(device=self.device)
+        ts = self._teacher_stream
+        ts.wait_stream(main)
+        with torch.cuda.stream(ts):
+            if self.move_data_to_gpu:
+                next_unsup = next_unsup.to(self.device, non_blocking=True)
+            pseudo = self._pseudo_label_generation(next_unsup)
+        self._prefetched = (i_next, [id(v) for v in next_unsup.values()], pseudo, ts)
+
+    def _take_prefetched(self, i, data_unsup):
+        pf, self._prefetched = self._prefetched, None
+        if pf is None or pf[0] != i or pf[1] != [id(v) for v in data_unsup.values()]:
+            return None
+        _, _, pseudo, ts = pf
+        main = torch.cuda.current_stream()
+        main.wait_stream(ts)
+        for v in pseudo.values():
+            if torch.is_tensor(v):
+                v.record_stream(main)
+        return pseudo
 
     # -- pieces (names follow the reference) --------------------------------------
     def _teacher_model_update(self, keep_rate=0.998):

@@ -67,6 +67,7 @@ class InputProjFn(torch.autograd.Function):
                  strideA=Cin * HW, strideC=HW * Cout, bias=bias)
         ctx.save_for_backward(feat, weight)
         ctx.params = (weight, bias)
+        ops._sink_expect(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         return out
 
     @staticmethod
