@@ -54,22 +54,22 @@ __device__ __forceinline__ int stage_plane(const float* __restrict__ g, int n, f
 // The tap-column loop is kept rolled so only one (R+HZ-1)-deep register window is live: ~50 VGPRs,
 // which lets six workgroups (24 waves) share a CU and keeps enough loads in flight to stream HBM.
 // Rows past the plane are never guarded: the LDS plane is over-allocated and those outputs are dropped.
-template <int HZ, int WZ>
+template <int HZ, int WZ, int RR = R>
 __device__ __forceinline__ void corr_column(const float* xs, int wx, const float* __restrict__ z, int i0, int col,
-                                            float (&r)[R]) {
+                                            float (&r)[RR]) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) r[k] = 0.f;
+    for (int k = 0; k < RR; ++k) r[k] = 0.f;
     const float* xp = xs + i0 * wx + col;
 #pragma unroll 1
     for (int v = 0; v < WZ; ++v) {
-        float xc[R + HZ - 1];
+        float xc[RR + HZ - 1];
 #pragma unroll
-        for (int k = 0; k < R + HZ - 1; ++k) xc[k] = xp[k * wx + v];
+        for (int k = 0; k < RR + HZ - 1; ++k) xc[k] = xp[k * wx + v];
 #pragma unroll
         for (int u = 0; u < HZ; ++u) {
             const float zv = z[u * WZ + v];
 #pragma unroll
-            for (int k = 0; k < R; ++k) r[k] = fmaf(xc[k + u], zv, r[k]);
+            for (int k = 0; k < RR; ++k) r[k] = fmaf(xc[k + u], zv, r[k]);
         }
     }
 }
@@ -292,6 +292,174 @@ __global__ __launch_bounds__(256) void groupdw_bwd_kernel(Branch b0, Branch b1, 
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Fast backward for the (5x5, 3x5, 5x3) template triple (NB = 3) or a single 5x5 template (NB = 1).
+//   dx: the forward's register-window walk over the zero-padded g with the reversed taps (9-row strips, so the
+//       45-row planes take one pass of the 256 threads);
+//   dz: every thread owns one (8-row strip, column) of g, keeps all HZ*WZ tap sums in registers while the
+//       window slides, and the 256 partial vectors are summed by a butterfly that halves the number of live
+//       values per lane at every step (32 shuffles per wave instead of 6 per tap), then across the four waves
+//       through LDS.
+// ---------------------------------------------------------------------------
+constexpr int RD = 9;       // dx rows per work item
+constexpr int TAPS = 32;    // tap slots of the reduction (25 used at most)
+
+// v[0..32) per lane -> lane l holds the 64-lane total of slot 16 b0 + 8 b1 + 4 b2 + 2 b3 + b4 (b_s = bit s of l)
+__device__ __forceinline__ float reduce_slots(float (&v)[TAPS], int lane) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int half = (TAPS >> s) >> 1;
+        const bool hi = (lane >> s) & 1;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            float lo_v = v[i], hi_v = v[half + i];
+            // keep the two elements in registers: folded into one lane-indexed load, the select would move the
+            // whole array to scratch memory
+            asm volatile("" : "+v"(lo_v), "+v"(hi_v));
+            const float keep = hi ? hi_v : lo_v;
+            const float send = hi ? lo_v : hi_v;
+            v[i] = keep + __shfl_xor(send, 1 << s);
+        }
+    }
+    return v[0] + __shfl_xor(v[0], 32);
+}
+__device__ __forceinline__ int slot_of_lane(int lane) {
+    return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+}
+
+template <int HZ, int WZ>
+__device__ __forceinline__ void dz_strip(const float* gcol, int gp_cols, const float* xcol, int wx, float (&acc)[TAPS]) {
+    float gk[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) gk[k] = gcol[k * gp_cols];
+#pragma unroll
+    for (int v = 0; v < WZ; ++v) {
+        float xc[R + HZ - 1];
+#pragma unroll
+        for (int k = 0; k < R + HZ - 1; ++k) xc[k] = xcol[k * wx + v];
+#pragma unroll
+        for (int u = 0; u < HZ; ++u) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < R; ++k) t = fmaf(gk[k], xc[k + u], t);
+            acc[u * WZ + v] = t;
+        }
+    }
+}
+
+// LDS floats of a staged x plane for the dz walk: rows up to (last strip) + R - 1 + hz - 1 are read
+__host__ __device__ inline int xplane_floats(int hx, int wx, int hz, int Ho) {
+    const int rows = ((Ho + R - 1) / R) * R + hz - 1;
+    return ((rows > hx ? rows : hx) * wx + 3 + 3) & ~3;
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 4) void groupdw_bwd5_kernel(Branch b0, Branch b1, Branch b2,
+                                                              const float* __restrict__ weight,
+                                                              const float* __restrict__ g, int Ho, int Wo,
+                                                              float* __restrict__ dx0, float* __restrict__ dx1,
+                                                              float* __restrict__ dx2, float* __restrict__ dz0,
+                                                              float* __restrict__ dz1, float* __restrict__ dz2,
+                                                              float* __restrict__ dsw_partial, int gp_rows, int gp_cols) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float zf[3][TAPS];          // reversed taps
+    __shared__ float red[4][TAPS];
+    constexpr int pad = 4;
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Branch br[3] = {b0, b1, b2};
+    float* dxs[3] = {dx0, dx1, dx2};
+    float* dzs[3] = {dz0, dz1, dz2};
+    float* gp = smem;
+    int off = (gp_rows * gp_cols + 3) & ~3;
+    float* xs[3];
+    // zero everything that is read but not loaded (padding of g, tails of the x planes), then stage
+    int total = off;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) total += xplane_floats(br[i].hx, br[i].wx, br[i].hz, Ho);
+    for (int i = tid; i < total; i += 256) smem[i] = 0.f;
+    if (tid < TAPS) {          // static branch index: a lane-dependent one would push the Branch array to scratch
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int nt = i < NB ? br[i].hz * br[i].wz : 0;
+            zf[i][tid] = tid < nt ? br[i].z[(size_t)p * nt + nt - 1 - tid] : 0.f;
+        }
+    }
+    __syncthreads();
+    const float* gsrc = g + (size_t)p * Ho * Wo;
+    for (int i = tid; i < Ho * Wo; i += 256) {
+        const int r = i / Wo, c = i - r * Wo;
+        gp[(r + pad) * gp_cols + c + pad] = gsrc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = br[i].hx * br[i].wx;
+        const int sh = stage_plane(br[i].x + (size_t)p * n, n, smem + off, tid);
+        xs[i] = smem + off + sh;
+        off += xplane_floats(br[i].hx, br[i].wx, br[i].hz, Ho);
+    }
+    float sw[3] = {1.f, 0.f, 0.f};
+    if (NB == 3) {
+        const float w0 = weight[0], w1 = weight[1], w2 = weight[2];
+        const float m = fmaxf(w0, fmaxf(w1, w2));
+        const float e0 = expf(w0 - m), e1 = expf(w1 - m), e2 = expf(w2 - m);
+        const float s = e0 + e1 + e2;
+        sw[0] = e0 / s; sw[1] = e1 / s; sw[2] = e2 / s;
+    }
+    __syncthreads();
+    // ---- dx_i = s_i * corr(padded g, reversed z_i)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        if (!dxs[i]) continue;
+        const int hx = br[i].hx, wx = br[i].wx;
+        float* op = dxs[i] + (size_t)p * hx * wx;
+        const int nstrip = (hx + RD - 1) / RD;
+        const float* origin = gp + (pad - (br[i].hz - 1)) * gp_cols + (pad - (br[i].wz - 1));
+        for (int item = tid; item < nstrip * wx; item += 256) {
+            const int strip = item / wx, col = item - strip * wx, a0 = strip * RD;
+            float r[RD];
+            if (i == 0) corr_column<5, 5, RD>(origin, gp_cols, zf[0], a0, col, r);
+            if (i == 1) corr_column<3, 5, RD>(origin, gp_cols, zf[1], a0, col, r);
+            if (i == 2) corr_column<5, 3, RD>(origin, gp_cols, zf[2], a0, col, r);
+#pragma unroll
+            for (int k = 0; k < RD; ++k)
+                if (a0 + k < hx) op[(a0 + k) * wx + col] = sw[i] * r[k];
+        }
+    }
+    // ---- dz_i and ds_i
+    const int nstrip = (Ho + R - 1) / R;
+    const bool active = tid < nstrip * Wo;
+    const int strip = tid / Wo, col = tid - strip * Wo, i0 = strip * R;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        float acc[TAPS];
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) acc[k] = 0.f;
+        if (active) {
+            const float* gcol = gp + (i0 + pad) * gp_cols + col + pad;
+            const float* xcol = xs[i] + i0 * br[i].wx + col;
+            if (i == 0) dz_strip<5, 5>(gcol, gp_cols, xcol, br[0].wx, acc);
+            if (i == 1) dz_strip<3, 5>(gcol, gp_cols, xcol, br[1].wx, acc);
+            if (i == 2) dz_strip<5, 3>(gcol, gp_cols, xcol, br[2].wx, acc);
+        }
+        const float tot = reduce_slots(acc, lane);
+        if (lane < 32) red[wave][slot_of_lane(lane)] = tot;
+        __syncthreads();
+        if (tid < 64) {
+            const int nt = br[i].hz * br[i].wz;
+            float t = 0.f, zs = 0.f;
+            if (tid < nt) {
+                t = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+                if (dzs[i]) dzs[i][(size_t)p * nt + tid] = sw[i] * t;
+                zs = zf[i][nt - 1 - tid] * t;          // z_i[tap] * raw dz
+            }
+            zs = wave_sum(zs);
+            if (NB == 3 && dsw_partial && tid == 0) dsw_partial[(size_t)p * 3 + i] = zs;
+        }
+        __syncthreads();
+    }
+}
+
 int launch_bwd(const Branch* b, int nb, const float* weight, const float* g, float** dx, float** dz, float* dsw,
                int planes, hipStream_t stream) {
     const int Ho = b[0].hx - b[0].hz + 1, Wo = b[0].wx - b[0].wz + 1;
@@ -301,6 +469,31 @@ int launch_bwd(const Branch* b, int nb, const float* weight, const float* g, flo
         pad = b[i].wz - 1 > pad ? b[i].wz - 1 : pad;
     }
     SPOT_CHECK_ARG(pad <= GPAD_MAX, "xcorr backward: template extent %d exceeds %d", pad + 1, GPAD_MAX + 1);
+    const bool five = b[0].hz == 5 && b[0].wz == 5 && ((Ho + R - 1) / R) * Wo <= 256;   // one dz item per thread
+    if (five) {
+        int rows = 0;
+        for (int i = 0; i < nb; ++i) {
+            const int need = ((b[i].hx + RD - 1) / RD) * RD + b[i].hz - 1 + (4 - (b[i].hz - 1));
+            rows = need > rows ? need : rows;
+        }
+        const int dzrows = ((Ho + R - 1) / R) * R + 2 * 4;
+        rows = dzrows > rows ? dzrows : rows;
+        const int gp_cols5 = Wo + 8;
+        size_t f5 = ((size_t)rows * gp_cols5 + 3) & ~(size_t)3;
+        for (int i = 0; i < nb; ++i) f5 += xplane_floats(b[i].hx, b[i].wx, b[i].hz, Ho);
+        if (f5 * sizeof(float) <= 64 * 1024) {
+            if (nb == 3)
+                groupdw_bwd5_kernel<3><<<planes, 256, f5 * sizeof(float), stream>>>(b[0], b[1], b[2], weight, g, Ho, Wo, dx[0],
+                                                                                   dx[1], dx[2], dz[0], dz[1], dz[2], dsw,
+                                                                                   rows, gp_cols5);
+            else
+                groupdw_bwd5_kernel<1><<<planes, 256, f5 * sizeof(float), stream>>>(b[0], b[1], b[2], weight, g, Ho, Wo, dx[0],
+                                                                                   dx[1], dx[2], dz[0], dz[1], dz[2], dsw,
+                                                                                   rows, gp_cols5);
+            SPOT_CHECK_LAUNCH("xcorr backward");
+            return SPOT_OK;
+        }
+    }
     int max_hx = 0;
     for (int i = 0; i < nb; ++i) max_hx = b[i].hx > max_hx ? b[i].hx : max_hx;
     // rows: every R-strip of dx may read R + hz - 1 rows starting at its origin

@@ -110,6 +110,16 @@ def bench_xcorr():
         ho = hx - hz + 1
         by = 4.0 * (sum(x.numel() for x in xs) + sum(z.numel() for z in zs) + B * Cn * ho * ho)
         print("%-12s B=%d  %8.1f us  %7.1f GB/s (%.3f GB)" % (tag, B, t * 1e6, by / t / 1e9, by / 1e9))
+        g = r(B, Cn, ho, ho)
+        dxs, dzs = [torch.empty_like(x) for x in xs], [torch.empty_like(z) for z in zs]
+        part = torch.empty(B * Cn, 3, device="cuda")
+        P = ops._p
+        tb = timeit(lambda: lib.call("spot_groupdw_bwd_f32", P(xs[0]), P(xs[1]), P(xs[2]), P(zs[0]), P(zs[1]), P(zs[2]),
+                                     P(w), P(g), P(dxs[0]), P(dxs[1]), P(dxs[2]), P(dzs[0]), P(dzs[1]), P(dzs[2]),
+                                     P(part), B * Cn, hx, hx, hz, hz, ops._st()))
+        bb = 4.0 * (2 * sum(x.numel() for x in xs) + 2 * sum(z.numel() for z in zs) + B * Cn * ho * ho)
+        print("%-12s backward     %8.1f us  %7.1f GB/s (%.3f GB: g, x, z in; dx, dz out)" % (tag, tb * 1e6, bb / tb / 1e9,
+                                                                                          bb / 1e9))
         t = timeit(lambda: ops.xcorr_depthwise(xs[0], zs[0]))
         by = 4.0 * (xs[0].numel() + zs[0].numel() + B * Cn * ho * ho)
         print("%-12s single xcorr %8.1f us  %7.1f GB/s" % (tag, t * 1e6, by / t / 1e9))
