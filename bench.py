@@ -179,9 +179,9 @@ def main():
     unsup_view = TensorDict(data_unsup)
     prefetch = os.environ.get("SPOT_PREFETCH_TEACHER", "1") == "1"
 
-    def step(i):
+    def step(i, lookahead=True):
         return trainer.train_iteration(i, TensorDict(data_sup), unsup_view, mid,
-                                       next_unsup=unsup_view if prefetch else None)
+                                       next_unsup=unsup_view if (prefetch and lookahead) else None)
 
     for i in range(args.warmup):
         step(i)
@@ -196,8 +196,9 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     ops.TIMER = None
-    # The fusion layers and the backbone run the template stream on a second HIP stream, so in the timed region a
-    # launch's duration includes the kernels that share the chip with it.  A short extra leg with the second
+    # The fusion layers and the backbone run the template stream on a second HIP stream and the next step's teacher
+    # pass runs beside the backward, so in the timed region a launch's duration includes the kernels that share
+    # the chip with it.  A short extra leg with the second
     # stream switched off gives each kernel's duration when it has the chip to itself (reported beside the
     # timed region's figure, never instead of it).
     exclusive = None
@@ -205,10 +206,10 @@ def main():
         from spot_amd import fusion
         two = fusion.TWO_STREAMS
         fusion.TWO_STREAMS = False
-        step(args.warmup + args.steps)          # settle into the serial schedule
+        step(args.warmup + args.steps, lookahead=False)          # settle into the serial schedule
         exclusive = ops.TIMER = ops.KernelTimer()
         for i in range(args.exclusive_steps):
-            step(args.warmup + args.steps + 1 + i)
+            step(args.warmup + args.steps + 1 + i, lookahead=False)
         torch.cuda.synchronize()
         ops.TIMER = None
         fusion.TWO_STREAMS = two
@@ -243,7 +244,8 @@ def main():
                         "achieved": round(xa, 2), "frac": round(xa / PEAK_F32_MFMA_TFLOPS, 4),
                         "avg_us": round(x["ms"] * 1e3 / x["launches"], 2), "launches": x["launches"],
                         "note": "same kernels in %d extra steps with the template stream serialised behind the "
-                                "search stream: a launch then has the chip to itself" % args.exclusive_steps}
+                                "search stream and no look-ahead teacher pass: a launch then has the chip to itself"
+                                % args.exclusive_steps}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args)

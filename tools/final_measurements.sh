@@ -1,0 +1,33 @@
+#!/bin/bash
+# The measurement set behind the numbers in the documentation: bench line, rocprofv3 kernel trace of the same
+# command (steady-state summary + whole-process stats), counter passes, kernel micro-benchmarks, other configs.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/final
+mkdir -p $O
+cd $R
+timeout -k 10 400 python3 bench.py > $O/bench.log 2>&1 || exit 1
+tail -c 600 $O/bench.log
+if [ "$1" = "quick" ]; then
+  rm -f $O/microbench.txt
+else
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline > $O/prof.log 2>&1 || exit 1
+cd $R
+f=$(ls $O/prof/*/*kernel_trace.csv | head -1)
+python3 profiles/summarize_trace.py $f 10 $O/steady.csv --skip-last 3 > $O/steady.txt || exit 1
+head -4 $O/steady.txt
+cp $(ls $O/prof/*/*kernel_stats.csv | head -1) $O/whole_process_kernel_stats.csv
+rm -rf $O/prof
+bash tools/collect_traffic.sh > $O/traffic.txt 2>&1 || exit 1
+cp gpurun_out/traffic.json $O/traffic.json
+echo traffic done
+fi
+for mode in "0 0" "0 0.1" "1 0.1"; do set -- $mode; SPOT_MB_BF16=$1 SPOT_MB_DROP=$2 timeout -k 10 100 python3 tools/microbench.py mha >> $O/microbench.txt 2>&1 || exit 1; done
+timeout -k 10 200 python3 tools/microbench.py gemm >> $O/microbench.txt 2>&1 || exit 1
+timeout -k 10 100 python3 tools/microbench.py xcorr >> $O/microbench.txt 2>&1 || exit 1
+timeout -k 10 100 python3 tools/microbench.py norm >> $O/microbench.txt 2>&1 || exit 1
+echo microbench done
+timeout -k 10 400 python3 tools/measure_configs.py > $O/configs.log 2>&1 || exit 1
+timeout -k 10 300 python3 bench.py --attention bf16 --clips 48 --sup 16 --no-cpu-baseline > $O/bench_cfg4.log 2>&1 || exit 1
+grep "^{" $O/configs.log | cut -c1-200
+echo all done
