@@ -15,6 +15,7 @@ stands in for cv2.resize (outside the parity contract, which is stated at the
 network boundary).
 """
 import math
+import os
 import time
 
 import numpy as np
@@ -65,7 +66,7 @@ class NetWithBackbone:
 
 
 class TransT_Tracker(object):
-    def __init__(self, name, net, window_penalty=0.49, exemplar_size=128, instance_size=256):
+    def __init__(self, name, net, window_penalty=0.49, exemplar_size=128, instance_size=256, use_graph=None):
         self.name = name
         self.net = net
         self.window_penalty = window_penalty
@@ -73,6 +74,14 @@ class TransT_Tracker(object):
         self.instance_size = instance_size
         self.mean = [0.485, 0.456, 0.406]
         self.std = [0.229, 0.224, 0.225]
+        # A frame is ~700 kernel launches at batch 1.  Optionally (use_graph=True or SPOT_TRACKER_GRAPH=1), from
+        # the third frame of a sequence on the whole device pipeline (normalise, backbone, fusion, heads, decode)
+        # replays as one captured HIP graph; frames 1-2 run eagerly and warm the convolution library's algorithm
+        # choice.  Measured on MI355X the frame time is the same either way (8.5-8.7 ms: the host already runs
+        # ahead of the GPU, whose ~700 small kernels take that long back to back), so it is off by default.
+        self.use_graph = (os.environ.get("SPOT_TRACKER_GRAPH", "0") == "1") if use_graph is None else bool(use_graph)
+        self._graph = None
+        self._eager_frames = 0
 
     def _bbox_clip(self, cx, cy, width, height, boundary):
         cx = max(0, min(cx, boundary[1]))
@@ -143,6 +152,7 @@ class TransT_Tracker(object):
         self.channel_average = np.mean(image, axis=(0, 1))
         z_crop = self.get_subwindow(image, self.center_pos, self.exemplar_size, s_z, self.channel_average)
         self.net.template(self._normalize(z_crop))
+        self._graph, self._eager_frames = None, 0       # the captured graph reads the previous template's features
         return {"time": time.time() - tic}
 
     def decode(self, outputs):
@@ -157,13 +167,51 @@ class TransT_Tracker(object):
                  ops._p(buf), ops._p(buf[6:]), B, L, ops._st())
         return buf
 
+    def _device_pipeline(self, x_crop):
+        """uint8 search crop -> decode buffer, everything on the device."""
+        return self.decode(self.net.track(self._normalize(x_crop)))
+
+    def _run_frame(self, x_crop):
+        if not self.use_graph:
+            return self._device_pipeline(x_crop)
+        if self._graph is None:
+            if self._eager_frames < 2:
+                self._eager_frames += 1
+                return self._device_pipeline(x_crop)
+            from . import fusion
+            two = fusion.TWO_STREAMS
+            try:
+                fusion.TWO_STREAMS = False                      # one stream inside the captured graph
+                self._x_static = x_crop.clone()
+                # one eager pass on the capture stream first: library handles and code objects that are created
+                # per stream on first use must exist before capture begins
+                cap = torch.cuda.Stream()
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cap):
+                    self._device_pipeline(self._x_static)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=cap):
+                    self._buf_static = self._device_pipeline(self._x_static)
+                self._graph = graph
+            except Exception as e:                              # capture unsupported: stay eager, say so once
+                import warnings
+                warnings.warn("spot_amd tracker: HIP graph capture failed (%s); running eagerly" % (e,))
+                torch.cuda.synchronize()
+                self.use_graph = False
+                return self._device_pipeline(x_crop)
+            finally:
+                fusion.TWO_STREAMS = two
+        self._x_static.copy_(x_crop)
+        self._graph.replay()
+        return self._buf_static
+
     def track(self, image, info: dict = None) -> dict:
         w_x = self.size[0] + (4 - 1) * ((self.size[0] + self.size[1]) * 0.5)
         h_x = self.size[1] + (4 - 1) * ((self.size[0] + self.size[1]) * 0.5)
         s_x = math.ceil(math.sqrt(w_x * h_x))
         x_crop = self.get_subwindow(image, self.center_pos, self.instance_size, round(s_x), self.channel_average)
-        outputs = self.net.track(self._normalize(x_crop))
-        res = self.decode(outputs).cpu().numpy()               # the frame's one device->host read
+        res = self._run_frame(x_crop).cpu().numpy()            # the frame's one device->host read
         bx, by, bw, bh = res[2:6]
         pscore = res[6:]
         bbox = np.array([bx, by, bw, bh], dtype=np.float32) * s_x

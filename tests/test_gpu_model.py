@@ -317,6 +317,29 @@ def test_tracker_post_processing_golden(golden):
         np.testing.assert_allclose(trk.size, g["size"][i], rtol=1e-6, atol=1e-3)
 
 
+def test_tracker_graph_replay_equals_eager():
+    """From the third frame the device pipeline replays as a captured graph: same boxes and score maps."""
+    from spot_amd.tracker import NetWithBackbone, TransT_Tracker
+    rng = np.random.default_rng(1)
+    frames = rng.integers(0, 255, size=(7, 256, 256, 3), dtype=np.uint8)
+    for y in range(7):
+        frames[y, 90 + 3 * y:150 + 3 * y, 100 + 2 * y:160 + 2 * y] = 235
+    runs = []
+    for use_graph in (False, True):
+        trk = TransT_Tracker("t", NetWithBackbone(net=build(1), use_gpu=True), 0.49, 128, 256, use_graph=use_graph)
+        trk.initialize(frames[0], {"init_bbox": [100.0, 90.0, 60.0, 60.0]})
+        runs.append([trk.track(f) for f in frames[1:]])
+        if use_graph:
+            assert trk._graph is not None
+            trk.initialize(frames[0], {"init_bbox": [100.0, 90.0, 60.0, 60.0]})     # new sequence: graph dropped
+            assert trk._graph is None
+            again = [trk.track(f) for f in frames[1:]]
+            np.testing.assert_allclose(again[-1]["target_bbox"], runs[-1][-1]["target_bbox"], rtol=1e-4, atol=1e-3)
+    for a, b in zip(*runs):
+        np.testing.assert_allclose(a["target_bbox"], b["target_bbox"], rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(a["best_score"], b["best_score"], rtol=1e-3, atol=1e-5)
+
+
 def test_tracker_runs_on_synthetic_sequence():
     """cfg-1 shape: 256x256 frames, template 128^2 cached once, track() per frame."""
     from spot_amd.tracker import NetWithBackbone, TransT_Tracker

@@ -43,7 +43,7 @@ def cfg1():
         el = time.perf_counter() - t0
     print(json.dumps({"config": "cfg1: tracker API, B=1, 49 track() calls on 256x256 frames incl. host crop, "
                                 "H2D, network, device decode, D2H", "value": round(49 / el, 2), "unit": "frames/s",
-                      "ms_per_frame": round(el / 49 * 1e3, 3)}))
+                      "ms_per_frame": round(el / 49 * 1e3, 3), "graph_replay": trk._graph is not None}))
 
 
 def cfg3():
