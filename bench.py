@@ -64,7 +64,11 @@ def build_job(args, rank):
     lr, wd, br = (S.optimizer_parameters[k] for k in ("learning_rate", "weight_decay", "backbone_ratio"))
     groups = [{"params": [p for n, p in stu.named_parameters() if "backbone" not in n and p.requires_grad]},
               {"params": [p for n, p in stu.named_parameters() if "backbone" in n and p.requires_grad], "lr": br * lr}]
-    opt = torch.optim.AdamW(groups, lr=lr, weight_decay=wd)
+    if os.environ.get("SPOT_TORCH_ADAMW", "0") == "1":
+        opt = torch.optim.AdamW(groups, lr=lr, weight_decay=wd)
+    else:
+        from spot_amd.optim import FlatAdamW
+        opt = FlatAdamW(groups, stu._spot_arena, lr=lr, weight_decay=wd)
     trainer = LTRSparseTrainer(actor, None, opt, S, SparseMiddleware(S))
     data_unsup, mid = unsup_batch(args.clips, 1 + rank, device="cuda")
     data_sup = sup_batch(args.sup, 1 + rank, device="cuda")

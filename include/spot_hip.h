@@ -276,6 +276,26 @@ int spot_batchnorm_bwd_f32(const float* dy, const float* x, const unsigned char*
                            const float* save_rstd, const float* gamma, float* dx, float* d_residual, float* dgamma,
                            float* dbeta, float* ws, int N, int C, int HW, int accumulate, hipStream_t stream);
 
+/* ---- AdamW over flat parameter storage (torch.optim.AdamW semantics: decoupled weight decay, no amsgrad; the
+ * reference's optimizer, ltr/train_settings/spot/spot_transt_003.py:148-157), one launch per step.
+ * The four buffers are parallel flat arrays; `chunks` (device memory) lists the trainable ranges, at most
+ * 4096 elements each, with the parameter group each belongs to. */
+typedef struct spot_adamw_chunk {
+    long offset;     /* first element */
+    int count;       /* elements (<= 4096 keeps workgroups balanced) */
+    int group;       /* index into the per-group arrays below, 0..3 */
+} spot_adamw_chunk;
+typedef struct spot_adamw_groups {
+    float lr[4];
+    float weight_decay[4];
+    float beta1, beta2, eps;
+    float bias_correction1;         /* 1 - beta1^step */
+    float sqrt_bias_correction2;    /* sqrt(1 - beta2^step) */
+} spot_adamw_groups;
+int spot_adamw_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                   const spot_adamw_chunk* chunks_dev, int n_chunks, const spot_adamw_groups* hyper,
+                   hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,7 @@ SIGNATURES = {
     "spot_batchnorm_apply_deferred": [vp, i32, vp],
     "spot_batchnorm_fwd_infer_f32": [vp] * 7 + [i32, i32, i32, f32, i32, vp],
     "spot_batchnorm_bwd_f32": [vp] * 11 + [i32, i32, i32, i32, vp],
+    "spot_adamw_f32": [vp, vp, vp, vp, vp, i32, vp, vp],
     "spot_gemm_f32": [C.POINTER(GemmDesc), vp],
     "spot_colsum_f32": [vp, i64, vp, i64, i32, vp],
     "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],

@@ -558,3 +558,40 @@ def test_batch_norm_act_fwd_bwd_vs_torch(ops, N, C, H, W):
             yr = ref(T(x).double()) + (T(r).double() if use_res else 0)
             yr = torch.relu(yr) if relu else yr
         np.testing.assert_allclose(ye.cpu().numpy(), yr.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_flat_adamw_matches_torch_adamw(ops):
+    """One-launch AdamW over the flat buffer vs torch.optim.AdamW: two groups with different learning rates,
+    odd-sized tensors, buffers in between that must stay untouched, three steps."""
+    from spot_amd.arena import ParamArena
+    from spot_amd.optim import FlatAdamW
+
+    def make():
+        torch.manual_seed(5)
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 7, 3), torch.nn.BatchNorm2d(7), torch.nn.Linear(5, 9),
+                                   torch.nn.Linear(9, 4099)).to(DEV)
+
+    a, b = make(), make()
+    arena = ParamArena(a, with_grads=True)
+    groups = lambda m: [{"params": [p for n, p in m.named_parameters() if not n.startswith("0.")]},
+                        {"params": [p for n, p in m.named_parameters() if n.startswith("0.")], "lr": 3e-4}]
+    oa = FlatAdamW(groups(a), arena, lr=2e-3, weight_decay=1e-2)
+    ob = torch.optim.AdamW(groups(b), lr=2e-3, weight_decay=1e-2)
+    rm0 = a[1].running_mean.clone()
+    for step in range(3):
+        for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            g = G(det_input(n, tuple(pa.shape), 10 + step, -1, 1))
+            pa.grad.copy_(g)
+            pb.grad = g.clone()
+        oa.step()
+        ob.step()
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=n)
+    assert torch.equal(a[1].running_mean, rm0)
+    oa.param_groups[0]["lr"] = 0.0            # schedulers act through param_groups
+    oa.param_groups[1]["lr"] = 0.0
+    oa.param_groups[0]["weight_decay"] = 0.0
+    oa.param_groups[1]["weight_decay"] = 0.0
+    before = arena.flat.clone()
+    oa.step()
+    assert torch.equal(before, arena.flat)
