@@ -94,22 +94,66 @@ struct Branch {
     int hx, wx, hz, wz;
 };
 
+// Register-staged variant of stage_plane for the persistent loop below: fetch() issues the plane's 16-byte
+// loads into NV float4 registers per thread (the loads stay in flight while the previous plane is being
+// correlated), commit() drops them into LDS.  Vector k of the 16-byte-aligned stream that contains the plane
+// lands at dst + 4k, i.e. plane element e at dst[shift + e].  Vectors that would cross the ends of the whole
+// tensor are read element-wise.
+template <int NV>
+struct PlaneRegs {
+    float4 v[NV];
+    int shift, nvec;
+    __device__ __forceinline__ void fetch(const float* __restrict__ tensor, long total, long first, int n, int tid) {
+        const float* g = tensor + first;
+        shift = (int)(((uintptr_t)g >> 2) & 3);
+        nvec = (shift + n + 3) >> 2;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = tid + 256 * i;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < nvec) {
+                const long e0 = first - shift + 4L * k;      // tensor-relative index of the vector's first float
+                if (e0 >= 0 && e0 + 3 < total) {
+                    v[i] = *reinterpret_cast<const float4*>(tensor + e0);
+                } else {
+                    if (e0 >= 0 && e0 < total) v[i].x = tensor[e0];
+                    if (e0 + 1 >= 0 && e0 + 1 < total) v[i].y = tensor[e0 + 1];
+                    if (e0 + 2 >= 0 && e0 + 2 < total) v[i].z = tensor[e0 + 2];
+                    if (e0 + 3 >= 0 && e0 + 3 < total) v[i].w = tensor[e0 + 3];
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = tid + 256 * i;
+            if (k < nvec) *reinterpret_cast<float4*>(dst + 4 * k) = v[i];
+        }
+    }
+};
+
 // KIND 0: runtime template sizes; KIND 5: Ocean's (5x5, 3x5, 5x3) triple.
-template <int NB, int KIND>
-__global__ __launch_bounds__(256, 6) void groupdw_kernel(Branch b0, Branch b1, Branch b2, const float* __restrict__ weight,
-                                                      float* __restrict__ out, int Ho, int Wo) {
+// Persistent workgroups: each walks planes blockIdx.x, blockIdx.x + gridDim.x, ...; the next plane's loads are
+// issued before the current plane is correlated, so every CU keeps HBM requests in flight all the time instead
+// of only during the load phase of whichever workgroups happen to be starting.
+// workgroups per CU the register budget is sized for: the staged planes take 4 * NB * NV registers per thread
+constexpr int wg_per_cu(int nb, int nv) { return nb * nv <= 2 ? 8 : (nb * nv <= 6 ? 4 : 2); }
+
+template <int NB, int KIND, int NV>
+__global__ __launch_bounds__(256, wg_per_cu(NB, NV)) void groupdw_kernel(Branch b0, Branch b1, Branch b2, const float* __restrict__ weight,
+                                                      float* __restrict__ out, int Ho, int Wo, int planes) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int p = blockIdx.x;
     const int tid = threadIdx.x;
     const Branch br[3] = {b0, b1, b2};
-    float* xs[3];
-    int off = 0;
+    int offs[3];
+    {
+        int off = 0;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int n = br[i].hx * br[i].wx;
-        const int sh = stage_plane(br[i].x + (size_t)p * n, n, smem + off, tid);
-        xs[i] = smem + off + sh;
-        off += plane_floats(br[i].hx, br[i].wx, br[i].hz);
+        for (int i = 0; i < NB; ++i) {
+            offs[i] = off;
+            off += plane_floats(br[i].hx, br[i].wx, br[i].hz);
+        }
     }
     float sw[3] = {1.f, 0.f, 0.f};
     if (NB == 3) {
@@ -119,32 +163,84 @@ __global__ __launch_bounds__(256, 6) void groupdw_kernel(Branch b0, Branch b1, B
         const float s = e0 + e1 + e2;
         sw[0] = e0 / s; sw[1] = e1 / s; sw[2] = e2 / s;
     }
-    __syncthreads();
-    const int nstrip = (Ho + R - 1) / R;
-    float* op = out + (size_t)p * Ho * Wo;
-    for (int item = tid; item < nstrip * Wo; item += 256) {
-        const int strip = item / Wo, col = item - strip * Wo;
-        const int i0 = strip * R;
-        float acc[R], r[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) acc[k] = 0.f;
+    PlaneRegs<NV> regs[NB];
+    int p = blockIdx.x;
+    if (p < planes) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const float* z = br[i].z + (size_t)p * br[i].hz * br[i].wz;
-            if (KIND == 5) {
-                if (i == 0) corr_column<5, 5>(xs[0], br[0].wx, z, i0, col, r);
-                if (i == 1) corr_column<3, 5>(xs[1], br[1].wx, z, i0, col, r);
-                if (i == 2) corr_column<5, 3>(xs[2], br[2].wx, z, i0, col, r);
-            } else {
-                corr_column_rt(xs[i], br[i].wx, z, br[i].hz, br[i].wz, i0, col, r);
+            const int n = br[i].hx * br[i].wx;
+            regs[i].fetch(br[i].x, (long)planes * n, (long)p * n, n, tid);
+        }
+    }
+    const int nstrip = (Ho + R - 1) / R;
+    for (; p < planes; p += gridDim.x) {
+        const float* xs[3];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            regs[i].commit(smem + offs[i], tid);
+            xs[i] = smem + offs[i] + regs[i].shift;
+        }
+        __syncthreads();
+        const int pn = p + gridDim.x;
+        if (pn < planes) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int n = br[i].hx * br[i].wx;
+                regs[i].fetch(br[i].x, (long)planes * n, (long)pn * n, n, tid);
+            }
+        }
+        float* op = out + (size_t)p * Ho * Wo;
+        for (int item = tid; item < nstrip * Wo; item += 256) {
+            const int strip = item / Wo, col = item - strip * Wo;
+            const int i0 = strip * R;
+            float acc[R], r[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const float* z = br[i].z + (size_t)p * br[i].hz * br[i].wz;
+                if (KIND == 5) {
+                    if (i == 0) corr_column<5, 5>(xs[0], br[0].wx, z, i0, col, r);
+                    if (i == 1) corr_column<3, 5>(xs[1], br[1].wx, z, i0, col, r);
+                    if (i == 2) corr_column<5, 3>(xs[2], br[2].wx, z, i0, col, r);
+                } else {
+                    corr_column_rt(xs[i], br[i].wx, z, br[i].hz, br[i].wz, i0, col, r);
+                }
+#pragma unroll
+                for (int k = 0; k < R; ++k) acc[k] = NB == 1 ? r[k] : __fadd_rn(acc[k], __fmul_rn(sw[i], r[k]));
             }
 #pragma unroll
-            for (int k = 0; k < R; ++k) acc[k] = NB == 1 ? r[k] : __fadd_rn(acc[k], __fmul_rn(sw[i], r[k]));
+            for (int k = 0; k < R; ++k)
+                if (i0 + k < Ho) op[(i0 + k) * Wo + col] = acc[k];
         }
-#pragma unroll
-        for (int k = 0; k < R; ++k)
-            if (i0 + k < Ho) op[(i0 + k) * Wo + col] = acc[k];
+        __syncthreads();       // everyone is done with this plane's LDS copy before the next commit
     }
+}
+
+// float4 registers per thread that hold one staged plane
+int plane_vectors(int hx, int wx) { return ((hx * wx + 3 + 3) / 4 + 255) / 256; }
+
+template <int NB, int KIND>
+int launch_fwd(const Branch* b, const float* weight, float* out, int planes, size_t lds, hipStream_t stream) {
+    const int Ho = b[0].hx - b[0].hz + 1, Wo = b[0].wx - b[0].wz + 1;
+    int nv = 0;
+    for (int i = 0; i < NB; ++i) nv = plane_vectors(b[i].hx, b[i].wx) > nv ? plane_vectors(b[i].hx, b[i].wx) : nv;
+    // as many workgroups as fit the chip at once (LDS- and register-limited), each walking several planes
+    const int lds_cap = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+#define SPOT_XC_LAUNCH(NVV)                                                                                      \
+    do {                                                                                                         \
+        int per_cu = wg_per_cu(NB, NVV) < lds_cap ? wg_per_cu(NB, NVV) : lds_cap;                                \
+        per_cu = per_cu < 1 ? 1 : per_cu;                                                                        \
+        const int grid = planes < 256 * per_cu ? planes : 256 * per_cu;                                          \
+        groupdw_kernel<NB, KIND, NVV><<<grid, 256, lds, stream>>>(b[0], b[1], b[2], weight, out, Ho, Wo, planes); \
+    } while (0)
+    if (nv <= 1) SPOT_XC_LAUNCH(1);
+    else if (nv <= 2) SPOT_XC_LAUNCH(2);
+    else if (nv <= 4) SPOT_XC_LAUNCH(4);
+    else if (nv <= 8) SPOT_XC_LAUNCH(8);
+    else SPOT_XC_LAUNCH(16);
+#undef SPOT_XC_LAUNCH
+    return 0;
 }
 
 size_t lds_bytes(const Branch* b, int nb) {
@@ -164,7 +260,8 @@ extern "C" int spot_xcorr_depthwise_f32(const float* x, const float* kernel, flo
     Branch b[3] = {{x, kernel, hx, wx, hz, wz}, {}, {}};
     const size_t lds = lds_bytes(b, 1);
     SPOT_CHECK_ARG(lds <= 64 * 1024, "xcorr_depthwise: search plane %dx%d does not fit the 64 KB LDS stage", hx, wx);
-    groupdw_kernel<1, 0><<<planes, 256, lds, stream>>>(b[0], b[1], b[2], nullptr, out, hx - hz + 1, wx - wz + 1);
+    SPOT_CHECK_ARG(((uintptr_t)x & 15) == 0, "xcorr_depthwise: x must be 16-byte aligned");
+    launch_fwd<1, 0>(b, nullptr, out, planes, lds, stream);
     SPOT_CHECK_LAUNCH("xcorr_depthwise");
     return SPOT_OK;
 }
@@ -180,11 +277,9 @@ extern "C" int spot_groupdw_f32(const float* x11, const float* x12, const float*
     Branch b[3] = {{x11, z11, hx, wx, hz, wz}, {x12, z12, hx - 2, wx, hz - 2, wz}, {x21, z21, hx, wx - 2, hz, wz - 2}};
     const size_t lds = lds_bytes(b, 3);
     SPOT_CHECK_ARG(lds <= 64 * 1024, "groupdw: search planes %dx%d do not fit the 64 KB LDS stage", hx, wx);
-    const int Ho = hx - hz + 1, Wo = wx - wz + 1;
-    if (hz == 5 && wz == 5)
-        groupdw_kernel<3, 5><<<planes, 256, lds, stream>>>(b[0], b[1], b[2], weight3, out, Ho, Wo);
-    else
-        groupdw_kernel<3, 0><<<planes, 256, lds, stream>>>(b[0], b[1], b[2], weight3, out, Ho, Wo);
+    SPOT_CHECK_ARG((((uintptr_t)x11 | (uintptr_t)x12 | (uintptr_t)x21) & 15) == 0, "groupdw: search planes must be 16-byte aligned");
+    if (hz == 5 && wz == 5) launch_fwd<3, 5>(b, weight3, out, planes, lds, stream);
+    else launch_fwd<3, 0>(b, weight3, out, planes, lds, stream);
     SPOT_CHECK_LAUNCH("groupdw");
     return SPOT_OK;
 }
