@@ -12,6 +12,7 @@ The nn.BatchNorm2d modules remain as parameter/buffer holders so state-dict
 keys match the reference.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -19,6 +20,10 @@ from torch import nn
 
 from . import ops
 from .tensordict import NestedTensor
+
+
+# 1x1 convolutions through this library's GEMM (ops.conv1x1) instead of the convolution library
+OWN_CONV1X1 = os.environ.get("SPOT_OWN_CONV1X1", "1") == "1"
 
 
 class Bottleneck(nn.Module):
@@ -38,10 +43,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = ops.batch_norm_act(self.conv1(x), self.bn1, relu=True)
+        c1 = ops.conv1x1 if (OWN_CONV1X1 and x.is_cuda) else (lambda t, conv: conv(t))
+        out = ops.batch_norm_act(c1(x, self.conv1), self.bn1, relu=True)
         out = ops.batch_norm_act(self.conv2(out), self.bn2, relu=True)
-        residual = x if self.downsample is None else ops.batch_norm_act(self.downsample[0](x), self.downsample[1])
-        return ops.batch_norm_act(self.conv3(out), self.bn3, relu=True, residual=residual)
+        residual = x if self.downsample is None else ops.batch_norm_act(c1(x, self.downsample[0]), self.downsample[1])
+        return ops.batch_norm_act(c1(out, self.conv3), self.bn3, relu=True, residual=residual)
 
 
 class ResNet50Layer3(nn.Module):

@@ -590,6 +590,67 @@ def layer_norm_infer(x, gamma, beta, eps=1e-5):
 
 
 # ---------------------------------------------------------------------------
+# 1x1 convolutions of the ResNet bottleneck as GEMMs on the NCHW maps
+# ---------------------------------------------------------------------------
+class Conv1x1Fn(torch.autograd.Function):
+    """y[b] = W x[b] for a bias-free 1x1 convolution, NCHW in and out (resnet.py:77,83,131-134).
+
+    Per clip the feature map is already a [C, H*W] row-major matrix, so forward, input gradient and weight
+    gradient are batched GEMMs on it as it lies: no NHWC round trip (the convolution library transposes
+    activations for its weight-gradient kernels), and the weight gradient is summed over the batch by
+    split-K straight into the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = _chk(x.contiguous())
+        B, Ci, H, W = x.shape
+        Co, HW = weight.shape[0], H * W
+        w2 = weight.view(Co, Ci)
+        y = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+        gemm(w2, x, y, Co, HW, Ci, transB=True, lda=Ci, ldb=HW, ldc=HW, batch=B, strideB=Ci * HW, strideC=Co * HW)
+        ctx.save_for_backward(x, weight)
+        ctx.params = (weight,)
+        if ctx.needs_input_grad[1]:
+            _sink_expect(weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        (pw,) = ctx.params
+        B, Ci, H, W = x.shape
+        Co, HW = weight.shape[0], H * W
+        w2 = weight.view(Co, Ci)
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(w2, dy, dx, Ci, HW, Co, transA=True, transB=True, lda=Ci, ldb=HW, ldc=HW, batch=B,
+                 strideB=Co * HW, strideC=Ci * HW)
+        if ctx.needs_input_grad[1]:
+            sk = _sink(pw)
+            dw = sk.view(Co, Ci) if sk is not None else torch.zeros_like(w2)
+            gemm(dy, x, dw, Co, Ci, B * HW, lda=HW, ldb=HW, ldc=Ci, kseg=HW, segA=Co * HW, segB=Ci * HW,
+                 splitk=_splitk_for(Co, Ci, B * HW), accumulate=True)
+            if sk is not None:
+                dw = None
+                _sink_done(pw)
+            else:
+                dw = dw.view_as(weight)
+        return dx, dw
+
+
+def conv1x1(x, conv):
+    """Bias-free 1x1 nn.Conv2d `conv` applied to x through the GEMM kernel (stride by subsampling first)."""
+    assert conv.kernel_size == (1, 1) and conv.bias is None and conv.groups == 1 and conv.padding == (0, 0)
+    if conv.stride != (1, 1):
+        x = x[:, :, ::conv.stride[0], ::conv.stride[1]]
+    if x.shape[2] * x.shape[3] % 32 != 0:       # the batch-summed weight gradient walks K in whole 32-wide tiles per clip
+        return torch.nn.functional.conv2d(x, conv.weight, None)
+    return Conv1x1Fn.apply(x, conv.weight)
+
+
+# ---------------------------------------------------------------------------
 # BatchNorm2d + ReLU (+ residual) of the ResNet bottleneck
 # ---------------------------------------------------------------------------
 class BatchNormActFn(torch.autograd.Function):

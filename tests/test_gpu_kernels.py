@@ -595,3 +595,23 @@ def test_flat_adamw_matches_torch_adamw(ops):
     before = arena.flat.clone()
     oa.step()
     assert torch.equal(before, arena.flat)
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,stride", [(3, 64, 256, 16, 16, 1), (2, 256, 64, 8, 8, 1), (2, 96, 40, 6, 6, 1),
+                                                (2, 128, 256, 16, 16, 2)])
+def test_conv1x1_as_gemm_vs_torch(ops, B, Ci, Co, H, W, stride):
+    conv = torch.nn.Conv2d(Ci, Co, 1, stride=stride, bias=False).to(DEV)
+    x = det_input("x", (B, Ci, H, W), 3, -1, 1)
+    with torch.no_grad():
+        conv.weight.copy_(G(det_input("w", (Co, Ci, 1, 1), 4, -0.2, 0.2)))
+    xg = G(x).requires_grad_()
+    y = ops.conv1x1(xg, conv)
+    up = det_input("up", tuple(y.shape), 5, -1, 1)
+    (y * G(up)).sum().backward()
+    xc = T(x).double().requires_grad_()
+    wc = conv.weight.detach().cpu().double().requires_grad_()
+    yc = torch.nn.functional.conv2d(xc, wc, None, stride=stride)
+    (yc * T(up).double()).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yc.detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), wc.grad.numpy(), rtol=1e-4, atol=1e-3)
