@@ -19,6 +19,9 @@ namespace {
 
 constexpr int R = 8;  // output rows per work item
 
+// float4 registers per thread that hold one staged plane
+int plane_vectors(int hx, int wx) { return ((hx * wx + 3 + 3) / 4 + 255) / 256; }
+
 // LDS floats reserved for one staged plane: the plane (+3 alignment shift) plus the rows the last,
 // partial strip of R output rows reads past the end (their results are discarded), 16-byte rounded.
 __host__ __device__ inline int plane_floats(int hx, int wx, int hz) {
@@ -217,8 +220,6 @@ __global__ __launch_bounds__(256, wg_per_cu(NB, NV)) void groupdw_kernel(Branch 
     }
 }
 
-// float4 registers per thread that hold one staged plane
-int plane_vectors(int hx, int wx) { return ((hx * wx + 3 + 3) / 4 + 255) / 256; }
 
 template <int NB, int KIND>
 int launch_fwd(const Branch* b, const float* weight, float* out, int planes, size_t lds, hipStream_t stream) {
@@ -243,6 +244,196 @@ int launch_fwd(const Branch* b, const float* weight, float* out, int planes, siz
     return 0;
 }
 
+
+
+// ---------------------------------------------------------------------------
+// Register-tile forward for a single 5x5 template (xcorr_depthwise); written for the (5x5, 3x5, 5x3) family.
+// The column walk above reads every input value WZ times from LDS (one 4-byte read per tap column), which
+// makes LDS issue, not HBM, the limit.  Here a thread owns a 4-row x 2-column output patch and loads its
+// (HZ+3) x (WZ+1) input patch once with 8-byte reads: 2.5x fewer LDS instructions per output.  8-byte reads
+// need even column starts and an even row stride, so the planes are re-pitched while they are committed to
+// LDS (stride wx rounded up to even) instead of being copied flat.
+// ---------------------------------------------------------------------------
+constexpr int TR = 4, TC = 2;
+
+__host__ __device__ inline int tile_stride(int wx) { return (wx + 1) & ~1; }
+// rows the last strip of TR output rows reads, at least the plane's own
+__host__ __device__ inline int tile_rows(int hx, int hz) {
+    const int ho = hx - hz + 1;
+    const int rows = ((ho + TR - 1) / TR) * TR + hz - 1;
+    return rows > hx ? rows : hx;
+}
+
+template <int NV>
+__device__ __forceinline__ void commit_pitched(const PlaneRegs<NV>& regs, float* dst, int n, int wx, int S, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k = tid + 256 * i;
+        if (k < regs.nvec) {
+            const int e0 = 4 * k - regs.shift;        // plane-relative index of the vector's first float
+            const float vals[4] = {regs.v[i].x, regs.v[i].y, regs.v[i].z, regs.v[i].w};
+            const int ec = e0 < 0 ? 0 : e0;
+            int r = ec / wx, c = ec - r * wx;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = e0 + j;
+                if (e >= 0 && e < n) {
+                    dst[r * S + c] = vals[j];
+                    if (++c == wx) {
+                        c = 0;
+                        ++r;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int HZ, int WZ>
+__device__ __forceinline__ void tile_corr(const float* xs, int S, const float* __restrict__ z, int i0, int j0,
+                                          float (&acc)[TR][TC]) {
+    float xp[HZ + TR - 1][WZ + TC - 1];
+    const float* base = xs + i0 * S + j0;
+#pragma unroll
+    for (int r = 0; r < HZ + TR - 1; ++r)
+#pragma unroll
+        for (int c = 0; c < WZ + TC - 1; c += 2) {
+            const float2 v = *reinterpret_cast<const float2*>(base + r * S + c);
+            xp[r][c] = v.x;
+            xp[r][c + 1] = v.y;
+        }
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+        for (int c = 0; c < TC; ++c) acc[r][c] = 0.f;
+#pragma unroll
+    for (int u = 0; u < HZ; ++u)
+#pragma unroll
+        for (int v = 0; v < WZ; ++v) {
+            const float zv = z[u * WZ + v];
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+#pragma unroll
+                for (int c = 0; c < TC; ++c) acc[r][c] = fmaf(xp[r + u][c + v], zv, acc[r][c]);
+        }
+}
+
+template <int NB, int NV>
+__global__ __launch_bounds__(256, NB == 1 ? 6 : 4) void groupdw_tile_kernel(Branch b0, Branch b1, Branch b2,
+                                                              const float* __restrict__ weight, float* __restrict__ out,
+                                                              int Ho, int Wo, int planes) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const Branch br[3] = {b0, b1, b2};
+    int offs[3], S[3];
+    {
+        int off = 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            offs[i] = off;
+            S[i] = tile_stride(br[i].wx);
+            off += (tile_rows(br[i].hx, br[i].hz) * S[i] + 3) & ~3;
+        }
+    }
+    float sw[3] = {1.f, 0.f, 0.f};
+    if (NB == 3) {
+        const float w0 = weight[0], w1 = weight[1], w2 = weight[2];
+        const float m = fmaxf(w0, fmaxf(w1, w2));
+        const float e0 = expf(w0 - m), e1 = expf(w1 - m), e2 = expf(w2 - m);
+        const float s = e0 + e1 + e2;
+        sw[0] = e0 / s; sw[1] = e1 / s; sw[2] = e2 / s;
+    }
+    // PERSIST: the workgroup walks several planes and keeps the next plane's loads in flight in registers while
+    // it correlates the current one.
+    constexpr bool PERSIST = NB == 1;
+    PlaneRegs<NV> regs[PERSIST ? NB : 1];
+    int p = blockIdx.x;
+    if (PERSIST && p < planes) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int n = br[i].hx * br[i].wx;
+            regs[i].fetch(br[i].x, (long)planes * n, (long)p * n, n, tid);
+        }
+    }
+    const int nsr = (Ho + TR - 1) / TR, nsc = (Wo + TC - 1) / TC;
+    for (; p < planes; p += gridDim.x) {
+        if (PERSIST) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                commit_pitched(regs[i], smem + offs[i], br[i].hx * br[i].wx, br[i].wx, S[i], tid);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int n = br[i].hx * br[i].wx;
+                PlaneRegs<NV> once;
+                once.fetch(br[i].x, (long)planes * n, (long)p * n, n, tid);
+                commit_pitched(once, smem + offs[i], n, br[i].wx, S[i], tid);
+            }
+        }
+        __syncthreads();
+        const int pn = p + gridDim.x;
+        if (PERSIST && pn < planes) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int n = br[i].hx * br[i].wx;
+                regs[i].fetch(br[i].x, (long)planes * n, (long)pn * n, n, tid);
+            }
+        }
+        float* op = out + (size_t)p * Ho * Wo;
+        for (int item = tid; item < nsr * nsc; item += 256) {
+            const int sr = item / nsc, sc = item - sr * nsc;
+            const int i0 = sr * TR, j0 = sc * TC;
+            float acc[TR][TC], r[TR][TC];
+#pragma unroll
+            for (int a = 0; a < TR; ++a)
+#pragma unroll
+                for (int c = 0; c < TC; ++c) acc[a][c] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const float* z = br[i].z + (size_t)p * br[i].hz * br[i].wz;
+                if (i == 0) tile_corr<5, 5>(smem + offs[0], S[0], z, i0, j0, r);
+                if (i == 1) tile_corr<3, 5>(smem + offs[1], S[1], z, i0, j0, r);
+                if (i == 2) tile_corr<5, 3>(smem + offs[2], S[2], z, i0, j0, r);
+#pragma unroll
+                for (int a = 0; a < TR; ++a)
+#pragma unroll
+                    for (int c = 0; c < TC; ++c) acc[a][c] = NB == 1 ? r[a][c] : __fadd_rn(acc[a][c], __fmul_rn(sw[i], r[a][c]));
+                // one branch's input patch at a time: without a fence for memory operations the scheduler hoists
+                // all three patches' LDS loads (116 registers) ahead of the arithmetic
+                if (NB > 1) asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int a = 0; a < TR; ++a)
+#pragma unroll
+                for (int c = 0; c < TC; ++c)
+                    if (i0 + a < Ho && j0 + c < Wo) op[(i0 + a) * Wo + j0 + c] = acc[a][c];
+        }
+        __syncthreads();
+    }
+}
+
+template <int NB>
+bool launch_tile(const Branch* b, const float* weight, float* out, int planes, hipStream_t stream) {
+    const int Ho = b[0].hx - b[0].hz + 1, Wo = b[0].wx - b[0].wz + 1;
+    size_t f = 0;
+    int nv = 0;
+    for (int i = 0; i < NB; ++i) {
+        f += ((size_t)tile_rows(b[i].hx, b[i].hz) * tile_stride(b[i].wx) + 3) & ~(size_t)3;
+        nv = plane_vectors(b[i].hx, b[i].wx) > nv ? plane_vectors(b[i].hx, b[i].wx) : nv;
+    }
+    // columns read past the plane: j0 + WZ + TC - 2 <= stride - 1 must hold for the last column patch
+    for (int i = 0; i < NB; ++i)
+        if (((Wo + TC - 1) / TC) * TC + b[i].wz - 1 > tile_stride(b[i].wx)) return false;
+    const size_t lds = f * sizeof(float);
+    if (lds > 40 * 1024 || nv > 2) return false;
+    const int lds_cap = (int)((160 * 1024) / lds), reg_cap = NB == 1 ? 6 : 4;
+    const int per_cu = lds_cap < reg_cap ? (lds_cap < 1 ? 1 : lds_cap) : reg_cap;
+    const int grid = (NB > 1 || planes < 256 * per_cu) ? planes : 256 * per_cu;     // the triple: one plane per workgroup
+    if (nv <= 1) groupdw_tile_kernel<NB, 1><<<grid, 256, lds, stream>>>(b[0], b[1], b[2], weight, out, Ho, Wo, planes);
+    else groupdw_tile_kernel<NB, 2><<<grid, 256, lds, stream>>>(b[0], b[1], b[2], weight, out, Ho, Wo, planes);
+    return true;
+}
+
 size_t lds_bytes(const Branch* b, int nb) {
     size_t f = 0;
     for (int i = 0; i < nb; ++i) f += plane_floats(b[i].hx, b[i].wx, b[i].hz);
@@ -261,7 +452,7 @@ extern "C" int spot_xcorr_depthwise_f32(const float* x, const float* kernel, flo
     const size_t lds = lds_bytes(b, 1);
     SPOT_CHECK_ARG(lds <= 64 * 1024, "xcorr_depthwise: search plane %dx%d does not fit the 64 KB LDS stage", hx, wx);
     SPOT_CHECK_ARG(((uintptr_t)x & 15) == 0, "xcorr_depthwise: x must be 16-byte aligned");
-    launch_fwd<1, 0>(b, nullptr, out, planes, lds, stream);
+    if (!(hz == 5 && wz == 5 && launch_tile<1>(b, nullptr, out, planes, stream))) launch_fwd<1, 0>(b, nullptr, out, planes, lds, stream);
     SPOT_CHECK_LAUNCH("xcorr_depthwise");
     return SPOT_OK;
 }
@@ -278,6 +469,8 @@ extern "C" int spot_groupdw_f32(const float* x11, const float* x12, const float*
     const size_t lds = lds_bytes(b, 3);
     SPOT_CHECK_ARG(lds <= 64 * 1024, "groupdw: search planes %dx%d do not fit the 64 KB LDS stage", hx, wx);
     SPOT_CHECK_ARG((((uintptr_t)x11 | (uintptr_t)x12 | (uintptr_t)x21) & 15) == 0, "groupdw: search planes must be 16-byte aligned");
+    // (the register-tile kernel is not used for the triple: three input patches plus the weighted sum do not fit
+    //  128 registers without spilling, and at 168 registers it loses to the column walk)
     if (hz == 5 && wz == 5) launch_fwd<3, 5>(b, weight3, out, planes, lds, stream);
     else launch_fwd<3, 0>(b, weight3, out, planes, lds, stream);
     SPOT_CHECK_LAUNCH("groupdw");
