@@ -64,3 +64,4 @@ def test_bucket_collectives_see_complete_gradients(monkeypatch):
             covered += n
         assert covered >= sum(p.numel() for p in net.parameters() if p.requires_grad)
         assert float(arena.grad_flat.abs().sum()) > 0
+
