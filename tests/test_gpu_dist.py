@@ -40,7 +40,7 @@ def test_bucket_collectives_see_complete_gradients(monkeypatch):
     S = Settings(dropout=0.0)
     net = det_fill_(transt_resnet50(Settings(device="cpu", dropout=0.0)), 17).cuda().train()
     arena = ParamArena(net, with_grads=True)
-    reducer = sdist.GradBucketReducer(arena, bucket_bytes=4 << 20, average=False)
+    reducer = sdist.GradBucketReducer(arena, bucket_bytes=4 << 20, average=False, overlap=True)
     assert len(reducer.buckets) > 5
     actor = TranstSparseActor(S, net, net, transt_loss(S))
     sup, sp = student_batches(17, 2, 6)
@@ -64,4 +64,5 @@ def test_bucket_collectives_see_complete_gradients(monkeypatch):
             covered += n
         assert covered >= sum(p.numel() for p in net.parameters() if p.requires_grad)
         assert float(arena.grad_flat.abs().sum()) > 0
+
 
