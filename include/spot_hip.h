@@ -165,6 +165,7 @@ typedef struct spot_gemm_desc {
     long ldres, strideRes;
     float drop_p;        /* dropout after relu and before mask/residual: v = keep ? v/(1-p) : 0; 0 = off */
     unsigned drop_seed;  /* mask = f(drop_seed, global row z*M + m, column n): see spot_dropout_f32 */
+    int tile;            /* workgroup tile: 0 = chosen from the problem shape, 64 = 64x64, 128 = 128x128 (same results) */
 } spot_gemm_desc;
 
 int spot_gemm_f32(const spot_gemm_desc* desc /* host */, hipStream_t stream);

@@ -10,7 +10,9 @@
 //   A: "MK" = A[m*lda + k]   or "KM" = A[k*lda + m]   (a transposed activation / NCHW feature map)
 //   B: "NK" = B[n*ldb + k]   (an nn.Linear weight)  or "KN" = B[k*ldb + n]
 // Tiling: 128x128x32 per 256-thread workgroup, 4 waves as 2x2, each wave a 2x2
-// grid of 32x32 MFMA tiles (64 accumulator VGPRs).  Tiles are staged
+// grid of 32x32 MFMA tiles (64 accumulator VGPRs); problems that would leave most
+// of the chip idle at that size (or whose M or N is 64) take a 64x64x32 tile, one
+// MFMA tile per wave.  Tiles are staged
 // global -> registers -> LDS: the next tile's global loads are issued before the
 // 64 MFMAs of the current one, the LDS writes after them.  LDS keeps the operand's own storage order
 // (k-contiguous rows padded to 36 floats for conflict-free 16-byte fragment
@@ -26,11 +28,17 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
+// TS = MFMA tiles per wave along m and along n: 2 -> 128x128 workgroup tile, 1 -> 64x64
+constexpr int BK = 32;
 constexpr int KPAD = BK + 4;    // k-contiguous LDS row stride (floats)
-constexpr int MPAD = BM + 4;    // m/n-contiguous LDS row stride (floats)
-constexpr int TILE_F = 128 * KPAD;  // floats per operand tile buffer (>= 32*MPAD)
-constexpr int CPAD = BN + 4;     // row stride of the epilogue's C staging tile (64 x CPAD floats <= 2*TILE_F)
+template <int TS> struct Tile {
+    static constexpr int BM = 64 * TS, BN = 64 * TS;
+    static constexpr int NL = 2 * TS;          // 16-byte loads per thread per operand tile
+    static constexpr int MPAD = BM + 4;        // m/n-contiguous LDS row stride (floats)
+    static constexpr int TILE_F = BM * KPAD;   // floats per operand tile buffer (>= 32*MPAD)
+    static constexpr int CPAD = BN + 4;        // row stride of the epilogue's C staging tile (64 x CPAD floats <= 2*TILE_F)
+    static constexpr int RSH = TS == 2 ? 5 : 4;   // log2(float4 per m/n-contiguous tile row)
+};
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -51,17 +59,18 @@ struct GemmArgs {
     unsigned drop_thr, drop_seed; float drop_scale;   // dropout after relu, before residual (0 = off)
 };
 
-template <int LAYOUT_KCONTIG, bool ALIGNED>
+template <int LAYOUT_KCONTIG, bool ALIGNED, int TS>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int r0, int k0, int R, int K,
-                                          float4 (&st)[4], int tid) {
-    // LAYOUT_KCONTIG: element (r,k) at P[r*ld + k], tile 128 rows x 32 k, float4 along k
-    // else          : element (r,k) at P[k*ld + r], tile 32 k x 128 rows, float4 along r
+                                          float4 (&st)[Tile<TS>::NL], int tid) {
+    // LAYOUT_KCONTIG: element (r,k) at P[r*ld + k], tile BM rows x 32 k, float4 along k
+    // else          : element (r,k) at P[k*ld + r], tile 32 k x BM rows, float4 along r
+    constexpr int RSH = Tile<TS>::RSH, RMASK = (1 << RSH) - 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < Tile<TS>::NL; ++i) {
         const int f = tid + 256 * i;
         int r, k;
         if (LAYOUT_KCONTIG) { r = r0 + (f >> 3); k = k0 + ((f & 7) << 2); }
-        else                { k = k0 + (f >> 5); r = r0 + ((f & 31) << 2); }
+        else                { k = k0 + (f >> RSH); r = r0 + ((f & RMASK) << 2); }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (LAYOUT_KCONTIG) {
             if (r < R) {
@@ -90,26 +99,30 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, 
     }
 }
 
-template <int LAYOUT_KCONTIG>
-__device__ __forceinline__ void store_tile(float* lds, const float4 (&st)[4], int tid) {
+template <int LAYOUT_KCONTIG, int TS>
+__device__ __forceinline__ void store_tile(float* lds, const float4 (&st)[Tile<TS>::NL], int tid) {
+    constexpr int RSH = Tile<TS>::RSH, RMASK = (1 << RSH) - 1, MPAD = Tile<TS>::MPAD;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < Tile<TS>::NL; ++i) {
         const int f = tid + 256 * i;
         if (LAYOUT_KCONTIG) *reinterpret_cast<float4*>(lds + (f >> 3) * KPAD + ((f & 7) << 2)) = st[i];
-        else                *reinterpret_cast<float4*>(lds + (f >> 5) * MPAD + ((f & 31) << 2)) = st[i];
+        else                *reinterpret_cast<float4*>(lds + (f >> RSH) * MPAD + ((f & RMASK) << 2)) = st[i];
     }
 }
 
 // fragment for one 32-row tile and one 8-wide k group: 4 floats, element j <-> k = g*8 + 4h + j
-template <int LAYOUT_KCONTIG>
+template <int LAYOUT_KCONTIG, int MPAD>
 __device__ __forceinline__ float4 read_frag(const float* lds, int row, int g, int h) {
     if (LAYOUT_KCONTIG) return *reinterpret_cast<const float4*>(lds + row * KPAD + g * 8 + 4 * h);
     const float* p = lds + (g * 8 + 4 * h) * MPAD + row;
     return make_float4(p[0], p[MPAD], p[2 * MPAD], p[3 * MPAD]);
 }
 
-template <int LA, int LB, bool ALIGNED>   // LA: 1 = MK (k-contiguous), 0 = KM;  LB: 1 = NK, 0 = KN
-__global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
+template <int LA, int LB, bool ALIGNED, int TS>   // LA: 1 = MK (k-contiguous), 0 = KM;  LB: 1 = NK, 0 = KN
+__global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) {
+    using T = Tile<TS>;
+    constexpr int BM = T::BM, BN = T::BN, NL = T::NL, MPAD = T::MPAD, TILE_F = T::TILE_F, CPAD = T::CPAD;
+    constexpr int RSH = T::RSH, RMASK = (1 << RSH) - 1, WT = 32 * TS;   // WT: rows (cols) of a wave's sub-tile
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE_F];
     float* const As = lds;
     float* const Bs = lds + TILE_F;
@@ -134,39 +147,39 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
     const int per = (nkt + g.splitk - 1) / g.splitk;
     const int kt0 = zs * per, kt1 = min(nkt, kt0 + per);
 
-    f32x16 acc[2][2];
+    f32x16 acc[TS][TS];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TS; ++t)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < TS; ++u)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
 
-    float4 sa[4], sb[4];
+    float4 sa[NL], sb[NL];
     auto fetch = [&](int kt) {
         const int k = kt * BK;
         const int seg = k / g.kseg, kin = k - seg * g.kseg;
-        load_tile<LA, ALIGNED>(A + seg * g.segA, g.lda, m0, kin, g.M, min(g.kseg, g.K - seg * g.kseg), sa, tid);
-        load_tile<LB, ALIGNED>(B + seg * g.segB, g.ldb, n0, kin, g.N, min(g.kseg, g.K - seg * g.kseg), sb, tid);
+        load_tile<LA, ALIGNED, TS>(A + seg * g.segA, g.lda, m0, kin, g.M, min(g.kseg, g.K - seg * g.kseg), sa, tid);
+        load_tile<LB, ALIGNED, TS>(B + seg * g.segB, g.ldb, n0, kin, g.N, min(g.kseg, g.K - seg * g.kseg), sb, tid);
     };
     // Interior tiles (whole 128x128 tile and every k tile in bounds, 16-byte aligned operands): the guarded
     // loader above costs a chain of ~90 branchy basic blocks per k tile; here a thread keeps four 32-bit
     // element offsets per operand and the k walk is one scalar base-pointer bump per tile.
-    unsigned offA[4], offB[4];
+    unsigned offA[NL], offB[NL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
         const int f = tid + 256 * i;
-        offA[i] = LA ? (unsigned)((m0 + (f >> 3)) * g.lda + ((f & 7) << 2)) : (unsigned)((f >> 5) * g.lda + m0 + ((f & 31) << 2));
-        offB[i] = LB ? (unsigned)((n0 + (f >> 3)) * g.ldb + ((f & 7) << 2)) : (unsigned)((f >> 5) * g.ldb + n0 + ((f & 31) << 2));
+        offA[i] = LA ? (unsigned)((m0 + (f >> 3)) * g.lda + ((f & 7) << 2)) : (unsigned)((f >> RSH) * g.lda + m0 + ((f & RMASK) << 2));
+        offB[i] = LB ? (unsigned)((n0 + (f >> 3)) * g.ldb + ((f & 7) << 2)) : (unsigned)((f >> RSH) * g.ldb + n0 + ((f & RMASK) << 2));
     }
     int fseg = (kt0 * BK) / g.kseg, fkin = kt0 * BK - fseg * g.kseg;     // position of the next tile to fetch
     auto fetch_fast = [&]() {
         const float* Ab = A + fseg * g.segA + (LA ? (long)fkin : (long)fkin * g.lda);
         const float* Bb = B + fseg * g.segB + (LB ? (long)fkin : (long)fkin * g.ldb);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sa[i] = *reinterpret_cast<const float4*>(Ab + offA[i]);
+        for (int i = 0; i < NL; ++i) sa[i] = *reinterpret_cast<const float4*>(Ab + offA[i]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sb[i] = *reinterpret_cast<const float4*>(Bb + offB[i]);
+        for (int i = 0; i < NL; ++i) sb[i] = *reinterpret_cast<const float4*>(Bb + offB[i]);
         fkin += BK;
         if (fkin >= g.kseg) {
             fkin = 0;
@@ -184,8 +197,8 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
         if (kt0 < kt1) {
             if (FAST) fetch_fast();
             else fetch(kt0);
-            store_tile<LA>(As, sa, tid);
-            store_tile<LB>(Bs, sb, tid);
+            store_tile<LA, TS>(As, sa, tid);
+            store_tile<LB, TS>(Bs, sb, tid);
         }
         __syncthreads();
         for (int kt = kt0; kt < kt1; ++kt) {
@@ -196,15 +209,15 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
             }
 #pragma unroll
             for (int gk = 0; gk < BK / 8; ++gk) {
-                float4 a[2], b[2];
+                float4 a[TS], b[TS];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) a[t] = read_frag<LA>(As, wm * 64 + t * 32 + l31, gk, h);
+                for (int t = 0; t < TS; ++t) a[t] = read_frag<LA, MPAD>(As, wm * WT + t * 32 + l31, gk, h);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) b[u] = read_frag<LB>(Bs, wn * 64 + u * 32 + l31, gk, h);
+                for (int u = 0; u < TS; ++u) b[u] = read_frag<LB, MPAD>(Bs, wn * WT + u * 32 + l31, gk, h);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < TS; ++t)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < TS; ++u) {
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
@@ -213,8 +226,8 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
             }
             __syncthreads();
             if (more) {
-                store_tile<LA>(As, sa, tid);
-                store_tile<LB>(Bs, sb, tid);
+                store_tile<LA, TS>(As, sa, tid);
+                store_tile<LB, TS>(Bs, sb, tid);
                 __syncthreads();
             }
         }
@@ -232,7 +245,8 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
     const float* res = (g.residual && first) ? g.residual + zb * g.strideRes : nullptr;
     const float* rowbias = first ? g.rowbias : nullptr;
     const float* bias = first ? g.bias : nullptr;
-    const int c4 = (tid & 31) << 2;
+    constexpr int CSH = RSH;                          // log2(float4 per staged C row)
+    const int c4 = (tid & RMASK) << 2;
     const int n = n0 + c4;
     const bool full = g.cvec && n + 3 < g.N;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -245,28 +259,29 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
             if (n + 3 < g.N) bv.w = bias[n + 3];
         }
     }
-    // the staging tile holds 64 rows at a time: rows of the wm = 0 waves first, then wm = 1
-    for (int half = 0; half < 2; ++half) {
+    // the staging tile holds 64 rows at a time: for the 128-row tile, rows of the wm = 0 waves first, then wm = 1
+    for (int half = 0; half < TS; ++half) {
         if (half) __syncthreads();
-        if (wm == half) {
+        if (TS == 1 || wm == half) {
+            const int rbase = TS == 1 ? wm * 32 : 0;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < TS; ++t)
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < TS; ++u)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        Cs[(t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CPAD + wn * 64 + u * 32 + l31] = acc[t][u][e];
+                        Cs[(rbase + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CPAD + wn * WT + u * 32 + l31] = acc[t][u][e];
         }
         __syncthreads();
         const int mh = m0 + half * 64;
         if (g.splitk > 1) {
             // split-K partial sums: one dword per lane, 64 consecutive floats per wave-instruction
             // (the shape float atomics run at full rate in)
-            const int col = tid & 127, nn = n0 + col;
+            const int col = tid & (BN - 1), nn = n0 + col;
             if (nn < g.N) {
                 const float b1 = bias ? bias[nn] : 0.f;
-                for (int i = 0; i < 32; ++i) {
-                    const int row = i * 2 + (tid >> 7), m = mh + row;
+                for (int i = 0; i < 64 / (256 / BN); ++i) {
+                    const int row = i * (256 / BN) + tid / BN, m = mh + row;
                     if (m >= g.M) break;
                     float x = Cs[row * CPAD + col] * g.alpha + b1;
                     if (rowbias) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + nn];
@@ -278,8 +293,8 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
         }
         if (n >= g.N) continue;
 #pragma unroll 4
-        for (int i = 0; i < 8; ++i) {
-            const int row = i * 8 + (tid >> 5);
+        for (int i = 0; i < (64 >> (8 - CSH)); ++i) {
+            const int row = (i << (8 - CSH)) + (tid >> CSH);
             const int m = mh + row;
             if (m >= g.M) break;
             float4 v = *reinterpret_cast<const float4*>(Cs + row * CPAD + c4);
@@ -334,12 +349,33 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// Workgroup tile for a problem.  Measured on MI355X the two tiles reach the same rate per FLOP (the 64x64 one
+// keeps six workgroups per CU in flight against three), so the choice is about quantisation: MFMA work is handed
+// out in workgroups, the last round of a grid leaves CUs idle, and a 64x64 workgroup is a quarter of the work.
+// The 128x128 tile (fewer epilogues, half the LDS traffic per FLOP) is kept for grids large enough that the tail
+// does not matter.
+int pick_tile(const GemmArgs& a, int batch, int forced) {
+    if (forced == 128) return 2;
+    if (forced == 64) return 1;
+    auto wgs = [&](int b) { return (long)((a.M + b - 1) / b) * ((a.N + b - 1) / b) * batch * a.splitk; };
+    const long CUS = 256;
+    const long w128 = wgs(128);
+    const long cost128 = 4 * ((w128 + CUS - 1) / CUS), cost64 = (wgs(64) + CUS - 1) / CUS;
+    return (cost64 < cost128 || w128 < 2048) ? 1 : 2;
+}
+
 template <int LA, int LB>
-int launch(const GemmArgs& a, int batch, bool aligned, hipStream_t stream) {
-    const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
+int launch(const GemmArgs& a, int batch, int tile, bool aligned, hipStream_t stream) {
+    const int ts = pick_tile(a, batch, tile), b = 64 * ts;
+    const int ntn = (a.N + b - 1) / b, ntm = (a.M + b - 1) / b;
     dim3 grid(ntm * ntn, 1, batch * a.splitk);
-    if (aligned) gemm_kernel<LA, LB, true><<<grid, 256, 0, stream>>>(a);
-    else gemm_kernel<LA, LB, false><<<grid, 256, 0, stream>>>(a);
+    if (ts == 2) {
+        if (aligned) gemm_kernel<LA, LB, true, 2><<<grid, 256, 0, stream>>>(a);
+        else gemm_kernel<LA, LB, false, 2><<<grid, 256, 0, stream>>>(a);
+    } else {
+        if (aligned) gemm_kernel<LA, LB, true, 1><<<grid, 256, 0, stream>>>(a);
+        else gemm_kernel<LA, LB, false, 1><<<grid, 256, 0, stream>>>(a);
+    }
     return 0;
 }
 
@@ -367,6 +403,7 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
     a.mask = d->mask; a.ldmask = d->ldmask;
     a.residual = d->residual; a.ldres = d->ldres; a.strideRes = d->strideRes;
     SPOT_CHECK_ARG(a.kseg % BK == 0 || a.kseg >= a.K, "gemm: kseg=%d must be a multiple of %d", a.kseg, BK);
+    SPOT_CHECK_ARG(d->tile == 0 || d->tile == 64 || d->tile == 128, "gemm: tile=%d (0, 64 or 128)", d->tile);
     SPOT_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p=%f outside [0,1)", d->drop_p);
     a.drop_thr = spot_drop_threshold(d->drop_p);
     a.drop_seed = d->drop_seed;
@@ -390,10 +427,10 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
     const long extA = ta ? (long)a.M * a.lda : (long)a.kseg * a.lda + a.M;
     const long extB = tb ? (long)a.N * a.ldb : (long)a.kseg * a.ldb + a.N;
     a.fast = aligned && a.K % BK == 0 && a.kseg % BK == 0 && extA < (1L << 31) && extB < (1L << 31);
-    if (ta && tb) launch<1, 1>(a, d->batch, aligned, stream);
-    else if (ta && !tb) launch<1, 0>(a, d->batch, aligned, stream);
-    else if (!ta && tb) launch<0, 1>(a, d->batch, aligned, stream);
-    else launch<0, 0>(a, d->batch, aligned, stream);
+    if (ta && tb) launch<1, 1>(a, d->batch, d->tile, aligned, stream);
+    else if (ta && !tb) launch<1, 0>(a, d->batch, d->tile, aligned, stream);
+    else if (!ta && tb) launch<0, 1>(a, d->batch, d->tile, aligned, stream);
+    else launch<0, 0>(a, d->batch, d->tile, aligned, stream);
     SPOT_CHECK_LAUNCH("gemm");
     return SPOT_OK;
 }

@@ -356,10 +356,13 @@ def _join_after_backward():
 # ---------------------------------------------------------------------------
 # dense contractions
 # ---------------------------------------------------------------------------
+_GEMM_TILE = int(os.environ.get("SPOT_GEMM_TILE", "0"))   # 0: the library picks per problem; 64 / 128 force one
+
+
 def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None, ldc=None, batch=1,
          strideA=0, strideB=0, strideC=0, kseg=0, segA=0, segB=0, splitk=1, alpha=1.0, accumulate=False,
          bias=None, rowbias=None, rb_rows=0, ldrb=0, relu=False, mask=None, ldmask=0, residual=None,
-         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0):
+         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0, tile=0):
     """Raw access to spot_gemm_f32; tensors are only used for their base pointers."""
     d = GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
@@ -380,6 +383,7 @@ def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None,
     d.residual = residual.data_ptr() if residual is not None else None
     d.ldres, d.strideRes = ldres, strideRes
     d.drop_p, d.drop_seed = drop_p, drop_seed
+    d.tile = tile or _GEMM_TILE
     if TIMER is not None:
         key = "gemm_%s%s" % ("t" if transA else "n", "n" if transB else "t")
         if TIMER.shapes:

@@ -193,16 +193,24 @@ def _ref_gemm(A, B, transA, transB):
 @pytest.mark.parametrize("transA", [False, True])
 @pytest.mark.parametrize("transB", [False, True])
 def test_gemm_layouts(ops, transA, transB):
-    for (M, N, K) in ((256, 256, 256), (384, 130, 96), (100, 2, 256), (37, 53, 19), (512, 768, 64)):
+    for (M, N, K) in ((256, 256, 256), (384, 130, 96), (100, 2, 256), (37, 53, 19), (512, 768, 64), (64, 320, 40)):
         A = det_input("A", (K, M) if transA else (M, K), 1, -1, 1)
         B = det_input("B", (K, N) if transB else (N, K), 2, -1, 1)
-        Cg = torch.empty((M, N), device=DEV)
-        ops.gemm(G(A), G(B), Cg, M, N, K, transA=transA, transB=transB)
         ref = _ref_gemm(T(A), T(B), transA, transB)
-        np.testing.assert_allclose(Cg.cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * math.sqrt(K))
+        got = {}
+        for tile in (0, 64, 128):
+            Cg = torch.empty((M, N), device=DEV)
+            ops.gemm(G(A), G(B), Cg, M, N, K, transA=transA, transB=transB, tile=tile)
+            np.testing.assert_allclose(Cg.cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * math.sqrt(K))
+            got[tile] = Cg.cpu()
+        # both workgroup tiles sum k in the same order: bit-identical results
+        assert torch.equal(got[64], got[128]) and torch.equal(got[0], got[128])
 
 
-def test_gemm_epilogues_splitk_segments(ops):
+@pytest.mark.parametrize("tile", [64, 128])
+def test_gemm_epilogues_splitk_segments(ops, tile):
+    import functools
+    ops = type("TiledOps", (), {"gemm": staticmethod(functools.partial(ops.gemm, tile=tile))})
     M, N, K = 512, 256, 384
     A, B = det_input("A", (M, K), 3, -1, 1), det_input("B", (N, K), 4, -1, 1)
     bias, rb = det_input("b", (N,), 5, -1, 1), det_input("rb", (128, N), 6, -1, 1)

@@ -74,6 +74,39 @@ def bench_gemm():
                                                                "sk=%d" % kw["splitk"] if "splitk" in kw else ""))
 
 
+def bench_gemm_tiles():
+    """The step's small / narrow problems under both workgroup tiles and the library's own choice."""
+    print("== gemm, 64x64 vs 128x128 workgroup tile (us)")
+    cases = [  # transA, transB, M, N, K, batch, splitk
+        (0, 0, 256, 256, 256, 1, 1), (0, 0, 1024, 256, 256, 1, 1), (0, 0, 8192, 256, 256, 1, 1),
+        (0, 0, 10240, 256, 256, 1, 1), (0, 1, 10240, 256, 256, 1, 1), (0, 0, 40960, 256, 256, 1, 1),
+        (0, 0, 256, 512, 256, 1, 1), (0, 0, 1024, 512, 256, 1, 1), (0, 0, 10240, 512, 256, 1, 1),
+        (0, 0, 10240, 256, 2048, 1, 1), (0, 1, 10240, 256, 2048, 1, 1), (0, 1, 10240, 2048, 256, 1, 1),
+        (0, 1, 10240, 256, 768, 1, 1), (0, 0, 10240, 768, 256, 1, 1),
+        (1, 1, 256, 256, 1024, 1, 4), (1, 1, 256, 256, 256, 1, 1), (1, 1, 256, 256, 10240, 1, 40),
+        (1, 1, 256, 256, 40960, 1, 128), (1, 1, 512, 256, 10240, 1, 40), (1, 1, 768, 256, 10240, 1, 40),
+        (1, 1, 2048, 256, 10240, 1, 16),
+        (0, 0, 256, 64, 163840, 1, 256), (0, 0, 64, 256, 163840, 1, 256), (0, 0, 512, 128, 40960, 1, 128),
+        (0, 0, 128, 512, 40960, 1, 128), (0, 0, 256, 64, 40960, 1, 160),
+        (1, 1, 64, 4096, 256, 40, 1), (0, 1, 256, 4096, 64, 40, 1), (0, 1, 64, 4096, 256, 40, 1),
+        (0, 1, 512, 1024, 128, 40, 1), (1, 1, 128, 1024, 512, 40, 1), (0, 1, 128, 1024, 512, 40, 1),
+        (1, 1, 256, 256, 1024, 40, 1), (0, 1, 256, 256, 1024, 40, 1), (0, 1, 1024, 256, 256, 40, 1),
+        (0, 0, 1024, 2048, 256, 1, 1), (0, 0, 1024, 256, 2048, 1, 1), (0, 0, 1024, 768, 256, 1, 1),
+        (0, 0, 256, 2048, 256, 1, 1), (0, 0, 256, 256, 2048, 1, 1),
+    ]
+    for ta, tb, M, N, K, batch, sk in cases:
+        A = r(K, M) if ta else r(M, K)
+        Bm = r(batch, K, N) if tb else r(batch, N, K)
+        Cc = torch.zeros(batch, M, N, device="cuda")
+        kw = dict(transA=bool(ta), transB=bool(tb), batch=batch, strideB=K * N if batch > 1 else 0,
+                  strideC=M * N if batch > 1 else 0, splitk=sk, accumulate=sk > 1)
+        t = {tile: timeit(lambda: ops.gemm(A, Bm, Cc, M, N, K, tile=tile, **kw)) * 1e6 for tile in (64, 128, 0)}
+        fl = 2.0 * M * N * K * batch
+        print("%s%s M=%6d N=%5d K=%6d b=%2d sk=%3d   64: %7.1f  128: %7.1f  auto: %7.1f (%5.1f TF)%s" % (
+            "t" if ta else "n", "n" if tb else "t", M, N, K, batch, sk, t[64], t[128], t[0], fl / t[0] / 1e6,
+            "   <-- auto picks the slower" if t[0] > 1.08 * min(t[64], t[128]) else ""))
+
+
 def bench_mha(shapes=((1024, 1024), (256, 256), (256, 1024), (1024, 256)), iters=20):
     pd = float(os.environ.get("SPOT_MB_DROP", "0"))
     bf16 = os.environ.get("SPOT_MB_BF16", "0") == "1"
@@ -151,7 +184,7 @@ def bench_norm():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     lib.load()
-    for name, fn in (("gemm", bench_gemm), ("mha", bench_mha), ("xcorr", bench_xcorr), ("norm", bench_norm)):
+    for name, fn in (("gemm", bench_gemm), ("gemm_tiles", bench_gemm_tiles), ("mha", bench_mha), ("xcorr", bench_xcorr), ("norm", bench_norm)):
         if what in (name, "all"):
             fn()
     if what == "mha1":      # one shape, few launches: for counter passes under rocprofv3 --pmc
