@@ -139,6 +139,7 @@ int spot_groupdw_f32(const float* x11, const float* x12, const float* x21, const
  *             B + s*segB with k counted from 0 again (a reduction that runs over several batch slabs).
  *   splitk > 1: K is split over splitk workgroups that add atomically into C (set accumulate = 1 and
  *             clear C first); not combinable with relu / mask.
+ *   rowsum: see the field.
  * Epilogue order: v = alpha*acc + bias[n] + rowbias[(m % rb_rows)*ldrb + n]; relu; dropout(drop_p, drop_seed);
  *                 v = mask[m*ldmask+n] > 0 ? v : 0; v += residual[m*ldres + n]; C = v or C += v. */
 typedef struct spot_gemm_desc {
@@ -166,6 +167,9 @@ typedef struct spot_gemm_desc {
     float drop_p;        /* dropout after relu and before mask/residual: v = keep ? v/(1-p) : 0; 0 = off */
     unsigned drop_seed;  /* mask = f(drop_seed, global row z*M + m, column n): see spot_dropout_f32 */
     int tile;            /* workgroup tile: 0 = chosen from the problem shape, 64 = 64x64, 128 = 128x128 (same results) */
+    float* rowsum;       /* [M] or null: rowsum[m] += sum_k opA(A)[m][k], added atomically (clear it first).  Only with
+                          * transA = transB = 1, batch = 1: the weight-gradient call dW = dY^T X, where this is the bias
+                          * gradient sum_rows dY (the sum nn.Linear's backward takes separately) */
 } spot_gemm_desc;
 
 int spot_gemm_f32(const spot_gemm_desc* desc /* host */, hipStream_t stream);

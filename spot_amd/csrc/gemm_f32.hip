@@ -57,6 +57,7 @@ struct GemmArgs {
     int cvec;                         // every epilogue operand allows 16-byte accesses
     int fast;                         // operands allow the unguarded interior-tile loader (see gemm_kernel)
     unsigned drop_thr, drop_seed; float drop_scale;   // dropout after relu, before residual (0 = off)
+    float* rowsum;                    // [M] += sum_k opA(A)[m][k] (atomic), or null
 };
 
 template <int LAYOUT_KCONTIG, bool ALIGNED, int TS>
@@ -118,7 +119,9 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int g, in
     return make_float4(p[0], p[MPAD], p[2 * MPAD], p[3 * MPAD]);
 }
 
-template <int LA, int LB, bool ALIGNED, int TS>   // LA: 1 = MK (k-contiguous), 0 = KM;  LB: 1 = NK, 0 = KN
+// ROWSUM: the workgroups of the first tile column also add the row sums of opA(A) into g.rowsum (the bias
+// gradient of a linear layer when A is the transposed output gradient: its tiles pass through here anyway).
+template <int LA, int LB, bool ALIGNED, int TS, bool ROWSUM>   // LA: 1 = MK (k-contiguous), 0 = KM;  LB: 1 = NK, 0 = KN
 __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) {
     using T = Tile<TS>;
     constexpr int BM = T::BM, BN = T::BN, NL = T::NL, MPAD = T::MPAD, TILE_F = T::TILE_F, CPAD = T::CPAD;
@@ -154,6 +157,11 @@ __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) 
         for (int u = 0; u < TS; ++u)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+    float rs[TS];
+#pragma unroll
+    for (int t = 0; t < TS; ++t) rs[t] = 0.f;
+    const bool do_rs = ROWSUM && n0 == 0 && wn == 0;
 
     float4 sa[NL], sb[NL];
     auto fetch = [&](int kt) {
@@ -214,6 +222,10 @@ __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) 
                 for (int t = 0; t < TS; ++t) a[t] = read_frag<LA, MPAD>(As, wm * WT + t * 32 + l31, gk, h);
 #pragma unroll
                 for (int u = 0; u < TS; ++u) b[u] = read_frag<LB, MPAD>(Bs, wn * WT + u * 32 + l31, gk, h);
+                if (ROWSUM && do_rs) {
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) rs[t] += (a[t].x + a[t].y) + (a[t].z + a[t].w);
+                }
 #pragma unroll
                 for (int t = 0; t < TS; ++t)
 #pragma unroll
@@ -234,6 +246,16 @@ __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) 
     };
     if (fast) k_loop(std::true_type{});
     else k_loop(std::false_type{});
+
+    if (ROWSUM && do_rs) {
+        // a lane holds the k = 4h..4h+3 (mod 8) share of row l31 of each of its MFMA row tiles
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+            const float v = rs[t] + __shfl_xor(rs[t], 32);
+            const int m = m0 + wm * WT + t * 32 + l31;
+            if (h == 0 && m < g.M) atomicAdd(g.rowsum + m, v);
+        }
+    }
 
     // epilogue.  Per-lane dword stores of the accumulator layout (32 floats per row segment) are
     // store-issue bound, so the tile is transposed through LDS (free after the k loop) and leaves
@@ -369,12 +391,23 @@ int launch(const GemmArgs& a, int batch, int tile, bool aligned, hipStream_t str
     const int ts = pick_tile(a, batch, tile), b = 64 * ts;
     const int ntn = (a.N + b - 1) / b, ntm = (a.M + b - 1) / b;
     dim3 grid(ntm * ntn, 1, batch * a.splitk);
+    if (LA == 0 && LB == 0 && a.rowsum) {      // the weight-gradient layout is the only one that asks for row sums
+        constexpr bool RS = LA == 0 && LB == 0;
+        if (ts == 2) {
+            if (aligned) gemm_kernel<LA, LB, true, 2, RS><<<grid, 256, 0, stream>>>(a);
+            else gemm_kernel<LA, LB, false, 2, RS><<<grid, 256, 0, stream>>>(a);
+        } else {
+            if (aligned) gemm_kernel<LA, LB, true, 1, RS><<<grid, 256, 0, stream>>>(a);
+            else gemm_kernel<LA, LB, false, 1, RS><<<grid, 256, 0, stream>>>(a);
+        }
+        return 0;
+    }
     if (ts == 2) {
-        if (aligned) gemm_kernel<LA, LB, true, 2><<<grid, 256, 0, stream>>>(a);
-        else gemm_kernel<LA, LB, false, 2><<<grid, 256, 0, stream>>>(a);
+        if (aligned) gemm_kernel<LA, LB, true, 2, false><<<grid, 256, 0, stream>>>(a);
+        else gemm_kernel<LA, LB, false, 2, false><<<grid, 256, 0, stream>>>(a);
     } else {
-        if (aligned) gemm_kernel<LA, LB, true, 1><<<grid, 256, 0, stream>>>(a);
-        else gemm_kernel<LA, LB, false, 1><<<grid, 256, 0, stream>>>(a);
+        if (aligned) gemm_kernel<LA, LB, true, 1, false><<<grid, 256, 0, stream>>>(a);
+        else gemm_kernel<LA, LB, false, 1, false><<<grid, 256, 0, stream>>>(a);
     }
     return 0;
 }
@@ -402,6 +435,9 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
     a.relu = d->relu;
     a.mask = d->mask; a.ldmask = d->ldmask;
     a.residual = d->residual; a.ldres = d->ldres; a.strideRes = d->strideRes;
+    a.rowsum = d->rowsum;
+    SPOT_CHECK_ARG(!a.rowsum || (d->transA && d->transB && d->batch == 1),
+                   "gemm: rowsum is for the weight-gradient layout (transA = transB = 1, batch = 1)");
     SPOT_CHECK_ARG(a.kseg % BK == 0 || a.kseg >= a.K, "gemm: kseg=%d must be a multiple of %d", a.kseg, BK);
     SPOT_CHECK_ARG(d->tile == 0 || d->tile == 64 || d->tile == 128, "gemm: tile=%d (0, 64 or 128)", d->tile);
     SPOT_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p=%f outside [0,1)", d->drop_p);

@@ -362,7 +362,7 @@ _GEMM_TILE = int(os.environ.get("SPOT_GEMM_TILE", "0"))   # 0: the library picks
 def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None, ldc=None, batch=1,
          strideA=0, strideB=0, strideC=0, kseg=0, segA=0, segB=0, splitk=1, alpha=1.0, accumulate=False,
          bias=None, rowbias=None, rb_rows=0, ldrb=0, relu=False, mask=None, ldmask=0, residual=None,
-         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0, tile=0):
+         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0, tile=0, rowsum=None):
     """Raw access to spot_gemm_f32; tensors are only used for their base pointers."""
     d = GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
@@ -384,6 +384,7 @@ def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None,
     d.ldres, d.strideRes = ldres, strideRes
     d.drop_p, d.drop_seed = drop_p, drop_seed
     d.tile = tile or _GEMM_TILE
+    d.rowsum = rowsum.data_ptr() if rowsum is not None else None
     if TIMER is not None:
         key = "gemm_%s%s" % ("t" if transA else "n", "n" if transB else "t")
         if TIMER.shapes:
@@ -444,8 +445,10 @@ def _splitk_for(rows_out, cols_out, k):
     return max(1, min(want, k // 256 if k >= 256 else 1))
 
 
-def linear_wgrad(dy2, x2, out=None, accumulate=False):
-    """dW[N,K] = dy2[M,N]^T x2[M,K], reduction over the M token rows split across workgroups."""
+def linear_wgrad(dy2, x2, out=None, accumulate=False, bias_out=None):
+    """dW[N,K] = dy2[M,N]^T x2[M,K], reduction over the M token rows split across workgroups.
+
+    bias_out [N] (+)= column sums of dy2 (the bias gradient), taken from the dy2 tiles the kernel stages anyway."""
     M, N = dy2.shape
     K = x2.shape[1]
     sk = _splitk_for(N, K, M)
@@ -454,8 +457,13 @@ def linear_wgrad(dy2, x2, out=None, accumulate=False):
     elif not accumulate:
         out.zero_()
     gemm(dy2, x2, out, N, K, M, transA=True, transB=True, lda=dy2.stride(0), ldb=x2.stride(0), ldc=out.stride(0),
-         splitk=sk, accumulate=True)
+         splitk=sk, accumulate=True, rowsum=bias_out)
     return out
+
+
+def _bias_grad_buffer(sink, n, device):
+    """Where a bias gradient is accumulated: the parameter's slice of the flat gradient buffer, or a cleared vector."""
+    return sink if sink is not None else torch.zeros((n,), dtype=torch.float32, device=device)
 
 
 def colsum(x2, out=None):
@@ -488,15 +496,19 @@ class LinearFn(torch.autograd.Function):
             dy2 = torch.where(y > 0, dy2, torch.zeros((), device=dy2.device))
         dx = linear_dgrad(dy2, W) if ctx.needs_input_grad[0] else None
         dW = db = None
+        want_b = pb is not None and ctx.needs_input_grad[2]
+        gb = _sink(pb) if want_b else None
+        if want_b and ctx.needs_input_grad[1]:          # bias gradient rides on the weight-gradient launch
+            db = _bias_grad_buffer(gb, W.shape[0], dy2.device)
         if ctx.needs_input_grad[1]:
             gW = _sink(pW)
-            dW = linear_wgrad(dy2, x2, out=gW, accumulate=gW is not None)
+            dW = linear_wgrad(dy2, x2, out=gW, accumulate=gW is not None, bias_out=db)
             if gW is not None:
                 dW = None
                 _sink_done(pW)
-        if pb is not None and ctx.needs_input_grad[2]:
-            gb = _sink(pb)
-            db = colsum(dy2, out=gb)
+        if want_b:
+            if db is None:
+                db = colsum(dy2, out=gb)
             if gb is not None:
                 db = None
                 _sink_done(pb)
@@ -534,10 +546,11 @@ class FFNFn(torch.autograd.Function):
         dh = linear_dgrad(dzd, W2, mask=h, alpha=1.0 / (1.0 - p))
         dx = linear_dgrad(dh, W1, residual=dz2)              # FFN path + residual path in one epilogue
         grads = []
-        for prm, dyv, xv in zip(ctx.params, (dh, dh, dzd, dzd), (x2, None, h, None)):
-            g = _sink(prm)
-            r = linear_wgrad(dyv, xv, out=g, accumulate=g is not None) if xv is not None else colsum(dyv, out=g)
-            grads.append(None if g is not None else r)
+        for (pw, pb), dyv, xv in zip(((ctx.params[0], ctx.params[1]), (ctx.params[2], ctx.params[3])), (dh, dzd), (x2, h)):
+            gw, gb = _sink(pw), _sink(pb)
+            db = _bias_grad_buffer(gb, pb.shape[0], dyv.device)
+            dw = linear_wgrad(dyv, xv, out=gw, accumulate=gw is not None, bias_out=db)
+            grads += [None if gw is not None else dw, None if gb is not None else db]
         _sink_done(*ctx.params)
         return (dx.view_as(dz), *grads, None)
 
@@ -881,8 +894,8 @@ class MHAFn(torch.autograd.Function):
         dattn = linear_dgrad(dzd, out_w)
         p_in_w, p_in_b, p_out_w, p_out_b = ctx.params
         sinks = [_sink(t) for t in ctx.params]
-        d_out_w = linear_wgrad(dzd, attn, out=sinks[2], accumulate=sinks[2] is not None)
-        d_out_b = colsum(dzd, out=sinks[3])
+        d_out_b = _bias_grad_buffer(sinks[3], Cn, dev)
+        d_out_w = linear_wgrad(dzd, attn, out=sinks[2], accumulate=sinks[2] is not None, bias_out=d_out_b)
         delta = torch.empty((B, nhead, Lq), dtype=torch.float32, device=dev)
         scale = 1.0 / math.sqrt(dh)
         d_in_w = sinks[0] if sinks[0] is not None else torch.zeros_like(in_w)
@@ -896,8 +909,7 @@ class MHAFn(torch.autograd.Function):
                 B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _st()))
             dxq = linear_dgrad(dqkv, in_w, residual=dz2 if has_res else None)
             dxkv = None
-            linear_wgrad(dqkv, xq2, out=d_in_w, accumulate=True)
-            colsum(dqkv, out=d_in_b)
+            linear_wgrad(dqkv, xq2, out=d_in_w, accumulate=True, bias_out=d_in_b)
             # (x + pos) W^T: the pos part of dW is (sum over clips of dq|dk)^T pos
             R = pos_q.shape[0]
             dqk_sum = dqkv[:, :2 * Cn].reshape(-1, R, 2 * Cn).sum(0) if R != dqkv.shape[0] else dqkv[:, :2 * Cn]
@@ -912,10 +924,8 @@ class MHAFn(torch.autograd.Function):
                 B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _st()))
             dxq = linear_dgrad(dq, in_w[:Cn], residual=dz2 if has_res else None)
             dxkv = linear_dgrad(dkv, in_w[Cn:])
-            linear_wgrad(dq, xq2, out=d_in_w[:Cn], accumulate=True)
-            linear_wgrad(dkv, xkv2, out=d_in_w[Cn:], accumulate=True)
-            colsum(dq, out=d_in_b[:Cn])
-            colsum(dkv, out=d_in_b[Cn:])
+            linear_wgrad(dq, xq2, out=d_in_w[:Cn], accumulate=True, bias_out=d_in_b[:Cn])
+            linear_wgrad(dkv, xkv2, out=d_in_w[Cn:], accumulate=True, bias_out=d_in_b[Cn:])
             Rq, Rk = pos_q.shape[0], pos_k.shape[0]
             dq_sum = dq.reshape(-1, Rq, Cn).sum(0) if Rq != dq.shape[0] else dq
             dk_sum = dkv[:, :Cn].reshape(-1, Rk, Cn).sum(0) if Rk != dkv.shape[0] else dkv[:, :Cn]

@@ -229,6 +229,21 @@ def test_gemm_epilogues_splitk_segments(ops, tile):
     Cg.zero_()
     ops.gemm(G(A), G(B), Cg, M, N, K, splitk=4, accumulate=True)
     np.testing.assert_allclose(Cg.cpu().double().numpy(), base.numpy(), rtol=1e-5, atol=1e-4)
+    # weight-gradient layout with the row sums of opA(A) (the bias gradient) taken on the way, plain and split-K
+    At, Bt = det_input("At", (K, M), 13, -1, 1), det_input("Bt", (K, N), 14, -1, 1)
+    for sk in (1, 3):
+        Cg.zero_()
+        rsum = torch.zeros((M,), device=DEV)
+        ops.gemm(G(At), G(Bt), Cg, M, N, K, transA=True, transB=True, splitk=sk, accumulate=True, rowsum=rsum)
+        np.testing.assert_allclose(Cg.cpu().double().numpy(), (T(At).double().t() @ T(Bt).double()).numpy(), rtol=1e-5,
+                                   atol=1e-4)
+        np.testing.assert_allclose(rsum.cpu().double().numpy(), T(At).double().sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    # ragged weight-gradient problem (guarded loader, partial tiles)
+    Ar, Br = det_input("Ar", (75, 100), 15, -1, 1), det_input("Br", (75, 37), 16, -1, 1)
+    Cr, rr = torch.zeros((100, 37), device=DEV), torch.zeros((100,), device=DEV)
+    ops.gemm(G(Ar), G(Br), Cr, 100, 37, 75, transA=True, transB=True, accumulate=True, rowsum=rr)
+    np.testing.assert_allclose(Cr.cpu().double().numpy(), (T(Ar).double().t() @ T(Br).double()).numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(rr.cpu().double().numpy(), T(Ar).double().sum(0).numpy(), rtol=1e-5, atol=1e-4)
     # batched
     Ab, Bb = det_input("Ab", (3, 64, 32), 9, -1, 1), det_input("Bb", (3, 48, 32), 10, -1, 1)
     Cb = torch.empty((3, 64, 48), device=DEV)
