@@ -173,8 +173,11 @@ def main():
     assert world == args.gpus, "launch with torchrun --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus)
     S, trainer, data_sup, data_unsup, mid = build_job(args, rank)
 
+    from spot_amd import dist as sdist
+    collective = sdist.active()          # more than one rank (or a forced one-rank rehearsal of that path)
+
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -217,7 +220,7 @@ def main():
         torch.cuda.synchronize()
         ops.TIMER = None
         fusion.TWO_STREAMS = two
-    if world > 1:
+    if collective:
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -262,7 +265,9 @@ def main():
             "config": {"workload": "cfg2: %d clips x 3 frames per GPU per step; teacher pseudo-label + decode + "
                                    "filter + compaction + student fwd/bwd/AdamW on %d labelled + %d pseudo-labelled "
                                    "pairs (TransT ResNet-50, 128^2 template / 256^2 search, fp32%s, student dropout %g, "
-                                   "brightness jitter 0.2, teacher in eval mode)"
+                                   "brightness jitter 0.2; the teacher stays in the module-default train() mode as in the "
+                                   "reference, whose actor only toggles the student: batch-statistics BatchNorm and "
+                                   "dropout are active in the pseudo-labelling pass too)"
                                    % (args.clips, args.sup, args.clips, "" if args.attention == "f32" else
                                       " with bf16 attention products", args.dropout),
                        "clips_per_gpu": args.clips, "sup_pairs_per_gpu": args.sup, "skipped_steps": args.steps - done,
@@ -270,7 +275,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

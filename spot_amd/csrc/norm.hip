@@ -128,23 +128,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-// dgamma|dbeta [2C] = sum over the nblk partial rows; 64 columns per workgroup, 4 waves split the rows
+// dgamma|dbeta [2C] (+)= sum over the nblk partial rows.  64 columns x 64 rows per workgroup (the 4 waves split
+// the rows, 4 loads in flight per lane); row groups are combined by atomic adds (at most nblk/64 per word), so the
+// destination is cleared beforehand unless it accumulates.
+constexpr int LN_RED_ROWS = 64;
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ partial, int nblk, int C2,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                        int accumulate) {
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (col < C2)
-        for (int r = wave; r < nblk; r += 4) s += partial[(size_t)r * C2 + col];
-    red[wave][lane] = s;
+    const int r0 = blockIdx.y * LN_RED_ROWS, r1 = min(nblk, r0 + LN_RED_ROWS);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < C2) {
+        int r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {
+            s0 += partial[(size_t)r * C2 + col];
+            s1 += partial[(size_t)(r + 4) * C2 + col];
+            s2 += partial[(size_t)(r + 8) * C2 + col];
+            s3 += partial[(size_t)(r + 12) * C2 + col];
+        }
+        for (; r < r1; r += 4) s0 += partial[(size_t)r * C2 + col];
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (wave == 0 && col < C2) {
         const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
         const int C = C2 >> 1;
-        if (col < C) { if (dgamma) dgamma[col] = accumulate ? dgamma[col] + t : t; }
-        else if (dbeta) dbeta[col - C] = accumulate ? dbeta[col - C] + t : t;
+        if (col < C) { if (dgamma) atomicAdd(dgamma + col, t); }
+        else if (dbeta) atomicAdd(dbeta + col - C, t);
     }
 }
 
@@ -188,7 +199,7 @@ extern "C" int spot_layernorm_fwd_f32(const float* x, const float* gamma, const 
 
 static int ln_bwd_grid(long rows) {
     long grid = (rows + 3) / 4;
-    return (int)(grid > 512 ? 512 : grid);
+    return (int)(grid > 1024 ? 1024 : grid);
 }
 
 extern "C" long spot_layernorm_bwd_ws_floats(long rows, int C) { return (long)ln_bwd_grid(rows) * 2 * C; }
@@ -213,7 +224,12 @@ extern "C" int spot_layernorm_bwd_f32(const float* dy, const float* x, const flo
     ln_bwd_kernel<<<grid, 256, 0, stream>>>(dy, x, mean, rstd, gamma, dx, want ? ws : nullptr, rows, C);
     SPOT_CHECK_LAUNCH("layernorm_bwd");
     if (want) {
-        ln_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, stream>>>(ws, grid, 2 * C, dgamma, dbeta, accumulate);
+        if (!accumulate) {
+            if (dgamma) (void)hipMemsetAsync(dgamma, 0, C * sizeof(float), stream);
+            if (dbeta) (void)hipMemsetAsync(dbeta, 0, C * sizeof(float), stream);
+        }
+        ln_reduce_kernel<<<dim3((2 * C + 63) / 64, (grid + LN_RED_ROWS - 1) / LN_RED_ROWS), 256, 0, stream>>>(
+            ws, grid, 2 * C, dgamma, dbeta);
         SPOT_CHECK_LAUNCH("layernorm_bwd(reduce)");
     }
     return SPOT_OK;

@@ -18,7 +18,7 @@ import torch.distributed as dist
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* when launched by torchrun."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not _FORCE:
         return 0, 1, 0
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
@@ -29,6 +29,16 @@ def init_from_env(backend=None):
     if not dist.is_initialized():
         dist.init_process_group(backend=backend)
     return rank, world, local
+
+
+# SPOT_FORCE_DIST=1: run the process group, barriers and bucket collectives even with a single rank (a one-GPU
+# rehearsal of the multi-rank code path; every collective is then an identity)
+_FORCE = os.environ.get("SPOT_FORCE_DIST", "0") == "1"
+
+
+def active():
+    """True when collectives are to be issued: more than one rank, or a forced single-rank rehearsal."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def world_size():
@@ -83,7 +93,8 @@ class GradBucketReducer:
         self._armed = False
         self._armed_before = False
         self._overlap = True
-        if self.world > 1:
+        self.active = self.world > 1 or active()
+        if self.active:
             for k, t, o in params:
                 t.register_post_accumulate_grad_hook(self._hook)
             arena.add_ready_listener(self._hook)     # gradients written into .grad by the kernels themselves
@@ -128,21 +139,21 @@ class GradBucketReducer:
 
     def finish(self):
         """Call after backward: launches buckets whose parameters got no gradient, waits, averages."""
-        if self.world <= 1:
+        if not self.active:
             return
         for b, left in enumerate(self.pending):
             if left != -1:
                 self._launch(b)
         for h in self.handles:
             h.wait()
-        if self.average:
+        if self.average and self.world > 1:
             self.arena.grad_flat.mul_(1.0 / self.world)
         self._armed = False
 
 
 def all_ranks_ok(flag_ok, device):
     """True only if every rank reports ok (keeps skip-iteration decisions rank-consistent)."""
-    if world_size() <= 1:
+    if not active():
         return bool(flag_ok)
     t = torch.tensor([1 if flag_ok else 0], dtype=torch.int32, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)

@@ -66,3 +66,59 @@ def test_bucket_collectives_see_complete_gradients(monkeypatch):
         assert float(arena.grad_flat.abs().sum()) > 0
 
 
+def test_rccl_single_rank_bucket_allreduce_is_identity(monkeypatch):
+    """The real RCCL path on one rank: communicator set-up, asynchronous all-reduce of slices of the flat gradient
+    buffer issued behind both compute streams, wait.  With one rank every collective is an identity, so the
+    gradients must equal those of a step taken without the reducer."""
+    import socket
+    import torch.distributed as dist
+    from spot_amd import dist as sdist
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.arena import ParamArena
+    from spot_amd.criterion import transt_loss
+    from spot_amd.detinit import det_fill_
+    from spot_amd.synthetic import Settings
+    from spot_amd.tensordict import TensorDict
+    from spot_amd.transt import transt_resnet50
+    from tests.test_oracle_model import student_batches
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        monkeypatch.setattr(sdist, "_FORCE", True)
+        assert sdist.active()
+        S = Settings(dropout=0.0)
+        net = det_fill_(transt_resnet50(Settings(device="cpu", dropout=0.0)), 19).cuda().train()
+        arena = ParamArena(net, with_grads=True)
+        actor = TranstSparseActor(S, net, net, transt_loss(S))
+        sup, sp = student_batches(19, 2, 4)
+        sup = TensorDict({k: v.cuda() for k, v in sup.items()})
+        sp = TensorDict({k: v.cuda() for k, v in sp.items()})
+
+        def grads(reducer):
+            arena.zero_grad()
+            loss, _ = actor(mode="spsup", burnin_data=TensorDict(sup), sp_data=TensorDict(sp))
+            if reducer is not None:
+                reducer.arm()
+            loss.backward()
+            if reducer is not None:
+                reducer.finish()
+            torch.cuda.synchronize()
+            return arena.grad_flat.clone()
+
+        base = grads(None)
+        for overlap in (False, True):
+            reducer = sdist.GradBucketReducer(arena, bucket_bytes=4 << 20, overlap=overlap)
+            assert reducer.active and len(reducer.buckets) > 5
+            for _ in range(2):                                  # early launches start with the second armed backward
+                got = grads(reducer)
+            nb = [k for k, _ in arena.f32 if "backbone" not in k]
+            # same tolerance as the run-to-run comparison of two plain steps (atomic summation order differs)
+            cos = torch.nn.functional.cosine_similarity(got, base, dim=0)
+            assert float(cos) > 0.9999, float(cos)
+            assert sdist.all_ranks_ok(True, "cuda") and not sdist.all_ranks_ok(False, "cuda")
+            assert len(nb) > 0
+    finally:
+        dist.destroy_process_group()
