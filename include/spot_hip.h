@@ -174,6 +174,18 @@ typedef struct spot_gemm_desc {
 
 int spot_gemm_f32(const spot_gemm_desc* desc /* host */, hipStream_t stream);
 
+/* Bias-free 3x3 convolution, stride 1, padding 1, dilation 1, NCHW fp32 (conv2 of the ResNet bottlenecks that
+ * neither stride nor dilate: ltr/models/backbone/resnet.py:79-81 with :61-62 defaults), by Winograd F(4x4, 3x3):
+ * weight / input transforms, 36 batched GEMMs on the matrix cores, output transform.  H and W multiples of 4.
+ *   flip = 0: out[B,Cout,H,W] = conv2d(in[B,Cin,H,W], w[Cout,Cin,3,3])                      (forward)
+ *   flip = 1: out[B,Cout,H,W] = conv_transpose2d(in[B,Cin,H,W], w[Cin,Cout,3,3])            (input gradient: in = dy,
+ *             w = the forward weight as stored, Cin = its output channels, Cout = its input channels)
+ * ws: spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W) floats of scratch.  Results differ from a direct
+ * convolution by fp32 rounding of the transforms (~1e-6 relative to the largest term). */
+long spot_conv3x3_winograd_ws_floats(int B, int Cin, int Cout, int H, int W);
+int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, int B, int Cin, int Cout, int H,
+                              int W, int flip, hipStream_t stream);
+
 /* nn.Dropout on a [rows, cols] tensor (transt_fusion.py:124,130-131,178,182,191-196) with a counter-based
  * mask keep(seed, row, col): out = keep ? x/(1-p) : 0.  The same (seed, row, col) function is used by the GEMM
  * epilogue, so the backward pass re-applies a forward mask by calling this on the incoming gradient. */

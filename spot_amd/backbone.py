@@ -45,7 +45,7 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         c1 = ops.conv1x1 if (OWN_CONV1X1 and x.is_cuda) else (lambda t, conv: conv(t))
         out = ops.batch_norm_act(c1(x, self.conv1), self.bn1, relu=True)
-        out = ops.batch_norm_act(self.conv2(out), self.bn2, relu=True)
+        out = ops.batch_norm_act(ops.conv3x3(out, self.conv2), self.bn2, relu=True)
         residual = x if self.downsample is None else ops.batch_norm_act(c1(x, self.downsample[0]), self.downsample[1])
         return ops.batch_norm_act(c1(out, self.conv3), self.bn3, relu=True, residual=residual)
 

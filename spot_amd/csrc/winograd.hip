@@ -1,0 +1,195 @@
+// 3x3 stride-1 convolutions of the ResNet bottlenecks (ltr/models/backbone/resnet.py:79-81: conv2 of every
+// block that neither strides nor dilates) by Winograd F(4x4, 3x3) in fp32, forward and input gradient.
+//
+// A 4x4 output tile needs 36 multiplications per (input channel, output channel) pair instead of 144, and in
+// the transformed domain those are 36 independent GEMMs  M_xi[co][p] = sum_ci U_xi[co][ci] V_xi[ci][p]
+// over p = (clip, tile), which run on the matrix cores through the library's GEMM:
+//   1. weights  U = G g G^T          [36][Cout][Cin]          (tiny)
+//   2. input    V = B^T d B          [36][Cin][P]             HBM-bound: reads the map once, writes 2.25x its size
+//   3. 36 batched GEMMs              [36][Cout][P]            fp32 MFMA, a quarter of the direct convolution's FLOPs
+//   4. output   y = A^T M A          [B][Cout][H][W]          HBM-bound: reads 2.25x the map, writes it once
+// The input gradient is the same computation with the filter rotated by 180 degrees and the channel roles
+// swapped (padding 1 stays padding 1), selected by `flip`.
+// In steps 2 and 4 a thread owns one tile of one channel; lanes run along p, so every access to V / M is a
+// coalesced 256-byte row segment per wave.
+#include "common.h"
+#include "../../include/spot_hip.h"
+
+namespace {
+
+constexpr int XI = 36;
+
+// column of B^T (6x6): interpolation points 0, +-1, +-2, inf
+__device__ __forceinline__ void bt6(const float d0, const float d1, const float d2, const float d3, const float d4,
+                                    const float d5, float (&o)[6]) {
+    o[0] = 4.f * d0 - 5.f * d2 + d4;
+    o[1] = -4.f * (d1 + d2) + d3 + d4;
+    o[2] = 4.f * (d1 - d2) - d3 + d4;
+    o[3] = 2.f * (d3 - d1) - d2 + d4;
+    o[4] = 2.f * (d1 - d3) - d2 + d4;
+    o[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+
+// column of A^T (4x6)
+__device__ __forceinline__ void at6(const float m0, const float m1, const float m2, const float m3, const float m4,
+                                    const float m5, float (&o)[4]) {
+    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+    o[0] = m0 + s12 + s34;
+    o[1] = d12 + 2.f * d34;
+    o[2] = s12 + 4.f * s34;
+    o[3] = d12 + 8.f * d34 + m5;
+}
+
+// U[xi][m][k] = (G g G^T)[xi];  flip = 0: g = w[m][k];  flip = 1: g = w[k][m] rotated by 180 degrees
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Mo,
+                                                           int Ki, int flip) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Mo * Ki) return;
+    const int m = idx / Ki, k = idx - m * Ki;
+    const float* gp = flip ? w + ((size_t)k * Mo + m) * 9 : w + ((size_t)m * Ki + k) * 9;
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = flip ? gp[(2 - a) * 3 + (2 - b)] : gp[a * 3 + b];
+    // rows of G: (1/4,0,0) (-1/6,-1/6,-1/6) (-1/6,1/6,-1/6) (1/24,1/12,1/6) (1/24,-1/12,1/6) (0,0,1)
+    float t[6][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float a = g[0][j], b = g[1][j], c = g[2][j];
+        t[0][j] = a * (1.f / 4.f);
+        t[1][j] = -(a + b + c) * (1.f / 6.f);
+        t[2][j] = (b - a - c) * (1.f / 6.f);
+        t[3][j] = a * (1.f / 24.f) + b * (1.f / 12.f) + c * (1.f / 6.f);
+        t[4][j] = a * (1.f / 24.f) - b * (1.f / 12.f) + c * (1.f / 6.f);
+        t[5][j] = c;
+    }
+    const size_t plane = (size_t)Mo * Ki;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const float a = t[i][0], b = t[i][1], c = t[i][2];
+        float* up = U + (size_t)(i * 6) * plane + idx;
+        up[0] = a * (1.f / 4.f);
+        up[plane] = -(a + b + c) * (1.f / 6.f);
+        up[2 * plane] = (b - a - c) * (1.f / 6.f);
+        up[3 * plane] = a * (1.f / 24.f) + b * (1.f / 12.f) + c * (1.f / 6.f);
+        up[4 * plane] = a * (1.f / 24.f) - b * (1.f / 12.f) + c * (1.f / 6.f);
+        up[5 * plane] = c;
+    }
+}
+
+// V[xi][c][p] = (B^T d B)[xi], d = the 6x6 input patch of tile p (rows 4ty-1 .. 4ty+4, zero outside the map)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int C, int H,
+                                                         int W, int P) {
+    const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (p >= P) return;
+    const int TW = W >> 2, T = (H >> 2) * TW;
+    const int b = p / T, t = p - b * T, ty = t / TW, tx = t - ty * TW;
+    const float* xp = x + ((size_t)b * C + c) * H * W;
+    const int c0 = 4 * tx;
+    float tmp[6][6];      // B^T d, built column by column after loading the patch rows
+    float d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int r = 4 * ty - 1 + i;
+        if (r >= 0 && r < H) {
+            const float* rp = xp + (size_t)r * W + c0;
+            const float4 mid = *reinterpret_cast<const float4*>(rp);
+            d[i][0] = c0 > 0 ? rp[-1] : 0.f;
+            d[i][1] = mid.x; d[i][2] = mid.y; d[i][3] = mid.z; d[i][4] = mid.w;
+            d[i][5] = c0 + 4 < W ? rp[4] : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) d[i][j] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float o[6];
+        bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][j] = o[i];
+    }
+    const size_t plane = (size_t)C * P;
+    float* vp = V + (size_t)c * P + p;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float o[6];
+        bt6(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], tmp[i][4], tmp[i][5], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) vp[(size_t)(i * 6 + j) * plane] = o[j];
+    }
+}
+
+// y tile = A^T M A
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, float* __restrict__ y, int C, int H,
+                                                          int W, int P) {
+    const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (p >= P) return;
+    const int TW = W >> 2, T = (H >> 2) * TW;
+    const int b = p / T, t = p - b * T, ty = t / TW, tx = t - ty * TW;
+    const size_t plane = (size_t)C * P;
+    const float* mp = Mb + (size_t)c * P + p;
+    float tmp[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float o[4];
+        at6(mp[(size_t)j * plane], mp[(size_t)(6 + j) * plane], mp[(size_t)(12 + j) * plane], mp[(size_t)(18 + j) * plane],
+            mp[(size_t)(24 + j) * plane], mp[(size_t)(30 + j) * plane], o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tmp[i][j] = o[i];
+    }
+    float* yp = y + ((size_t)b * C + c) * H * W + (size_t)(4 * ty) * W + 4 * tx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float o[4];
+        at6(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], tmp[i][4], tmp[i][5], o);
+        *reinterpret_cast<float4*>(yp + (size_t)i * W) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+struct Sizes {
+    long U, V, M;
+};
+Sizes sizes(int B, int Cin, int Cout, int H, int W) {
+    const long P = (long)B * (H / 4) * (W / 4);
+    return {(long)XI * Cout * Cin, (long)XI * Cin * P, (long)XI * Cout * P};
+}
+
+}  // namespace
+
+extern "C" long spot_conv3x3_winograd_ws_floats(int B, int Cin, int Cout, int H, int W) {
+    const Sizes s = sizes(B, Cin, Cout, H, W);
+    return s.U + s.V + s.M;
+}
+
+extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, int B, int Cin, int Cout,
+                                         int H, int W, int flip, hipStream_t stream) {
+    SPOT_CHECK_ARG(in && w && out && ws, "conv3x3_winograd: null pointer");
+    SPOT_CHECK_ARG(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_winograd: bad shape");
+    SPOT_CHECK_ARG(H % 4 == 0 && W % 4 == 0, "conv3x3_winograd: H=%d, W=%d must be multiples of 4", H, W);
+    SPOT_CHECK_ARG((((uintptr_t)in | (uintptr_t)out | (uintptr_t)ws) & 15) == 0, "conv3x3_winograd: buffers must be 16-byte aligned");
+    const long Pl = (long)B * (H / 4) * (W / 4);
+    SPOT_CHECK_ARG(Pl * (long)(Cin > Cout ? Cin : Cout) * XI < (1L << 40) && Pl < (1L << 31), "conv3x3_winograd: problem too large");
+    const int P = (int)Pl;
+    const Sizes s = sizes(B, Cin, Cout, H, W);
+    float* U = ws;
+    float* V = U + s.U;
+    float* Mb = V + s.V;
+    wino_weights_kernel<<<spot_ceil_div((long)Cout * Cin, 256), 256, 0, stream>>>(w, U, Cout, Cin, flip);
+    SPOT_CHECK_LAUNCH("conv3x3_winograd(weights)");
+    wino_input_kernel<<<dim3(spot_ceil_div(P, 256), Cin), 256, 0, stream>>>(in, V, Cin, H, W, P);
+    SPOT_CHECK_LAUNCH("conv3x3_winograd(input)");
+    spot_gemm_desc d = {};
+    d.A = U; d.B = V; d.C = Mb;
+    d.M = Cout; d.N = P; d.K = Cin; d.batch = XI;
+    d.transA = 0; d.transB = 1;
+    d.lda = Cin; d.ldb = P; d.ldc = P;
+    d.strideA = (long)Cout * Cin; d.strideB = (long)Cin * P; d.strideC = (long)Cout * P;
+    d.splitk = 1; d.alpha = 1.f;
+    const int rc = spot_gemm_f32(&d, stream);
+    if (rc != SPOT_OK) return rc;
+    wino_output_kernel<<<dim3(spot_ceil_div(P, 256), Cout), 256, 0, stream>>>(Mb, out, Cout, H, W, P);
+    SPOT_CHECK_LAUNCH("conv3x3_winograd(output)");
+    return SPOT_OK;
+}

@@ -668,6 +668,54 @@ def conv1x1(x, conv):
 
 
 # ---------------------------------------------------------------------------
+# 3x3 convolutions of the ResNet bottleneck
+# ---------------------------------------------------------------------------
+def _winograd(inp, weight, Cout, flip):
+    B, Cin, H, W = inp.shape
+    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=inp.device)
+    ws = torch.empty((lib.load().spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W),), dtype=torch.float32,
+                     device=inp.device)
+    lib.call("spot_conv3x3_winograd_f32", _p(inp), _p(weight), _p(out), _p(ws), B, Cin, Cout, H, W, int(flip), _st())
+    return out
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """Bias-free 3x3 convolution, stride 1, padding 1 (resnet.py:79-81): forward and input gradient by the
+    Winograd F(4x4, 3x3) path of the library; the weight gradient stays with the convolution library."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = _chk(x.contiguous())
+        ctx.save_for_backward(x, weight)
+        return _winograd(x, weight, weight.shape[0], flip=False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = _winograd(dy, weight, weight.shape[1], flip=True) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     (False, True, False))[1]
+        return dx, dw
+
+
+_WINOGRAD_MIN_TILES = int(os.environ.get("SPOT_WINOGRAD_MIN_TILES", "512"))   # below: too little work per transformed GEMM
+
+
+def conv3x3(x, conv):
+    """nn.Conv2d `conv` applied to x: the Winograd path for bias-free 3x3 / stride 1 / padding 1 / dilation 1
+    convolutions on maps whose sides are multiples of 4, the convolution library otherwise."""
+    B, _, H, W = x.shape
+    if (_WINOGRAD_MIN_TILES >= 0 and x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and H % 4 == 0 and W % 4 == 0 and B * (H // 4) * (W // 4) >= _WINOGRAD_MIN_TILES):
+        return Conv3x3Fn.apply(x, conv.weight)
+    return conv(x)
+
+
+# ---------------------------------------------------------------------------
 # BatchNorm2d + ReLU (+ residual) of the ResNet bottleneck
 # ---------------------------------------------------------------------------
 class BatchNormActFn(torch.autograd.Function):
