@@ -186,6 +186,13 @@ long spot_conv3x3_winograd_ws_floats(int B, int Cin, int Cout, int H, int W);
 int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, int B, int Cin, int Cout, int H,
                               int W, int flip, hipStream_t stream);
 
+/* Weight gradient of the same convolution in the transformed domain: dw[Cout,Cin,3,3] (+)= G^T (sum over tiles of
+ * (A dY A^T) (B^T d B)) G, the tile sum being 36 batched GEMMs.  x [B,Cin,H,W] is the forward input, dy [B,Cout,H,W]
+ * the output gradient; accumulate = 1 adds into dw (a slice of a gradient buffer). */
+long spot_conv3x3_winograd_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W);
+int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout,
+                                    int H, int W, int accumulate, hipStream_t stream);
+
 /* nn.Dropout on a [rows, cols] tensor (transt_fusion.py:124,130-131,178,182,191-196) with a counter-based
  * mask keep(seed, row, col): out = keep ? x/(1-p) : 0.  The same (seed, row, col) function is used by the GEMM
  * epilogue, so the backward pass re-applies a forward mask by calling this on the incoming gradient. */

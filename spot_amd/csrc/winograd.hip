@@ -148,6 +148,90 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 }
 
+// column of A (6x4): the output-gradient tile enters the transformed domain through the transpose of A^T
+__device__ __forceinline__ void a4(const float y0, const float y1, const float y2, const float y3, float (&o)[6]) {
+    const float e = y0 + y2, f = y1 + y3, g4 = y0 + 4.f * y2, h = 2.f * y1 + 8.f * y3;
+    o[0] = y0;
+    o[1] = e + f;
+    o[2] = e - f;
+    o[3] = g4 + h;
+    o[4] = g4 - h;
+    o[5] = y3;
+}
+
+// dM[xi][c][p] = (A dY A^T)[xi], dY = the 4x4 output-gradient tile p of channel c
+__global__ __launch_bounds__(256) void wino_outgrad_kernel(const float* __restrict__ dy, float* __restrict__ dM, int C,
+                                                           int H, int W, int P) {
+    const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (p >= P) return;
+    const int TW = W >> 2, T = (H >> 2) * TW;
+    const int b = p / T, t = p - b * T, ty = t / TW, tx = t - ty * TW;
+    const float* yp = dy + ((size_t)b * C + c) * H * W + (size_t)(4 * ty) * W + 4 * tx;
+    float4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(yp + (size_t)i * W);
+    float tmp[6][4];
+    {
+        float o[6];
+        a4(r[0].x, r[1].x, r[2].x, r[3].x, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][0] = o[i];
+        a4(r[0].y, r[1].y, r[2].y, r[3].y, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][1] = o[i];
+        a4(r[0].z, r[1].z, r[2].z, r[3].z, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][2] = o[i];
+        a4(r[0].w, r[1].w, r[2].w, r[3].w, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][3] = o[i];
+    }
+    const size_t plane = (size_t)C * P;
+    float* mp = dM + (size_t)c * P + p;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float o[6];
+        a4(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) mp[(size_t)(i * 6 + j) * plane] = o[j];
+    }
+}
+
+// row of G^T (3x6)
+__device__ __forceinline__ void gt6(const float u0, const float u1, const float u2, const float u3, const float u4,
+                                    const float u5, float (&o)[3]) {
+    const float s12 = u1 + u2, s34 = u3 + u4;
+    o[0] = u0 * (1.f / 4.f) - s12 * (1.f / 6.f) + s34 * (1.f / 24.f);
+    o[1] = (u2 - u1) * (1.f / 6.f) + (u3 - u4) * (1.f / 12.f);
+    o[2] = (s34 - s12) * (1.f / 6.f) + u5;
+}
+
+// dw[m][k][3][3] (+)= G^T dU[.][m][k] G
+__global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Mo,
+                                                             int Ki, int accumulate) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Mo * Ki) return;
+    const size_t plane = (size_t)Mo * Ki;
+    const float* up = dU + idx;
+    float tmp[3][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float o[3];
+        gt6(up[(size_t)j * plane], up[(size_t)(6 + j) * plane], up[(size_t)(12 + j) * plane], up[(size_t)(18 + j) * plane],
+            up[(size_t)(24 + j) * plane], up[(size_t)(30 + j) * plane], o);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) tmp[a][j] = o[a];
+    }
+    float* wp = dw + (size_t)idx * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float o[3];
+        gt6(tmp[a][0], tmp[a][1], tmp[a][2], tmp[a][3], tmp[a][4], tmp[a][5], o);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) wp[a * 3 + b] = accumulate ? wp[a * 3 + b] + o[b] : o[b];
+    }
+}
+
 struct Sizes {
     long U, V, M;
 };
@@ -191,5 +275,50 @@ extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float*
     if (rc != SPOT_OK) return rc;
     wino_output_kernel<<<dim3(spot_ceil_div(P, 256), Cout), 256, 0, stream>>>(Mb, out, Cout, H, W, P);
     SPOT_CHECK_LAUNCH("conv3x3_winograd(output)");
+    return SPOT_OK;
+}
+
+extern "C" long spot_conv3x3_winograd_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W) {
+    return spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W);
+}
+
+extern "C" int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int B, int Cin,
+                                               int Cout, int H, int W, int accumulate, hipStream_t stream) {
+    SPOT_CHECK_ARG(x && dy && dw && ws, "conv3x3_winograd_wgrad: null pointer");
+    SPOT_CHECK_ARG(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_winograd_wgrad: bad shape");
+    SPOT_CHECK_ARG(H % 4 == 0 && W % 4 == 0, "conv3x3_winograd_wgrad: H=%d, W=%d must be multiples of 4", H, W);
+    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15) == 0, "conv3x3_winograd_wgrad: buffers must be 16-byte aligned");
+    const long Pl = (long)B * (H / 4) * (W / 4);
+    SPOT_CHECK_ARG(Pl * (long)(Cin > Cout ? Cin : Cout) * XI < (1L << 40) && Pl < (1L << 31), "conv3x3_winograd_wgrad: problem too large");
+    const int P = (int)Pl;
+    const Sizes s = sizes(B, Cin, Cout, H, W);
+    float* dU = ws;
+    float* V = dU + s.U;
+    float* dM = V + s.V;
+    wino_input_kernel<<<dim3(spot_ceil_div(P, 256), Cin), 256, 0, stream>>>(x, V, Cin, H, W, P);
+    SPOT_CHECK_LAUNCH("conv3x3_winograd_wgrad(input)");
+    wino_outgrad_kernel<<<dim3(spot_ceil_div(P, 256), Cout), 256, 0, stream>>>(dy, dM, Cout, H, W, P);
+    SPOT_CHECK_LAUNCH("conv3x3_winograd_wgrad(output gradient)");
+    // dU[xi][co][ci] = sum_p dM[xi][co][p] V[xi][ci][p]: the tile index is the reduction; split it when the 36 output
+    // matrices alone give too few workgroups
+    const long wgs = (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * XI;
+    int sk = (int)((1536 + wgs - 1) / wgs);
+    if (sk > P / 256) sk = P / 256;
+    if (sk < 1) sk = 1;
+    if (sk > 1 && hipMemsetAsync(dU, 0, (size_t)s.U * sizeof(float), stream) != hipSuccess) {
+        spot_set_error("conv3x3_winograd_wgrad: clearing the workspace failed");
+        return SPOT_ERR_LAUNCH;
+    }
+    spot_gemm_desc d = {};
+    d.A = dM; d.B = V; d.C = dU;
+    d.M = Cout; d.N = Cin; d.K = P; d.batch = XI;
+    d.transA = 0; d.transB = 0;
+    d.lda = P; d.ldb = P; d.ldc = Cin;
+    d.strideA = (long)Cout * P; d.strideB = (long)Cin * P; d.strideC = (long)Cout * Cin;
+    d.splitk = sk; d.accumulate = sk > 1; d.alpha = 1.f;
+    const int rc = spot_gemm_f32(&d, stream);
+    if (rc != SPOT_OK) return rc;
+    wino_wgrad_out_kernel<<<spot_ceil_div((long)Cout * Cin, 256), 256, 0, stream>>>(dU, dw, Cout, Cin, accumulate);
+    SPOT_CHECK_LAUNCH("conv3x3_winograd_wgrad(weights)");
     return SPOT_OK;
 }

@@ -63,6 +63,7 @@ SIGNATURES = {
     "spot_gemm_f32": [C.POINTER(GemmDesc), vp],
     "spot_colsum_f32": [vp, i64, vp, i64, i32, vp],
     "spot_conv3x3_winograd_f32": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "spot_conv3x3_winograd_wgrad_f32": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
     "spot_mha_bwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64,
                          i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
@@ -98,6 +99,8 @@ def load():
     lib.spot_batchnorm_ws_floats.argtypes = [i32, i32]
     lib.spot_conv3x3_winograd_ws_floats.restype = i64
     lib.spot_conv3x3_winograd_ws_floats.argtypes = [i32, i32, i32, i32, i32]
+    lib.spot_conv3x3_winograd_wgrad_ws_floats.restype = i64
+    lib.spot_conv3x3_winograd_wgrad_ws_floats.argtypes = [i32, i32, i32, i32, i32]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.restype = i32

@@ -681,24 +681,44 @@ def _winograd(inp, weight, Cout, flip):
 
 class Conv3x3Fn(torch.autograd.Function):
     """Bias-free 3x3 convolution, stride 1, padding 1 (resnet.py:79-81): forward and input gradient by the
-    Winograd F(4x4, 3x3) path of the library; the weight gradient stays with the convolution library."""
+    Winograd F(4x4, 3x3) path of the library; the weight gradient likewise (summed in the transformed domain and
+    added straight into the flat gradient buffer), or by the convolution library with SPOT_WINOGRAD_WGRAD=0."""
 
     @staticmethod
     def forward(ctx, x, weight):
         x = _chk(x.contiguous())
         ctx.save_for_backward(x, weight)
+        ctx.params = (weight,)
+        if ctx.needs_input_grad[1] and _WINOGRAD_WGRAD:
+            _sink_expect(weight)
         return _winograd(x, weight, weight.shape[0], flip=False)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        (pw,) = ctx.params
         dy = dy.contiguous()
         dx = _winograd(dy, weight, weight.shape[1], flip=True) if ctx.needs_input_grad[0] else None
         dw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _WINOGRAD_WGRAD:
             dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                      (False, True, False))[1]
+        elif ctx.needs_input_grad[1]:
+            B, Cin, H, W = x.shape
+            Cout = weight.shape[0]
+            sk = _sink(pw)
+            dw = sk if sk is not None else torch.empty_like(weight)
+            ws = torch.empty((lib.load().spot_conv3x3_winograd_wgrad_ws_floats(B, Cin, Cout, H, W),), dtype=torch.float32,
+                             device=x.device)
+            lib.call("spot_conv3x3_winograd_wgrad_f32", _p(x), _p(dy), _p(dw), _p(ws), B, Cin, Cout, H, W,
+                     int(sk is not None), _st())
+            if sk is not None:
+                dw = None
+                _sink_done(pw)
         return dx, dw
+
+
+_WINOGRAD_WGRAD = os.environ.get("SPOT_WINOGRAD_WGRAD", "1") == "1"
 
 
 _WINOGRAD_MIN_TILES = int(os.environ.get("SPOT_WINOGRAD_MIN_TILES", "512"))   # below: too little work per transformed GEMM

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 from torch.nn.grad import conv2d_input, conv2d_weight
 
 from tools.microbench import timeit
+from spot_amd import lib, ops
 
 B = int(os.environ.get("SPOT_CB_BATCH", "40"))
 shapes = []   # name, Cin, Cout, H(in), k, stride, pad, dil, count per stream pass
@@ -21,7 +22,7 @@ for tag, S in (("search", 256), ("template", 128)):
                (tag + " l3.0 3x3 d2", 256, 256, S // 8, 3, 1, 2, 2, 1),
                (tag + " l3 3x3", 256, 256, S // 8, 3, 1, 1, 1, 5)]
 tot = [0.0, 0.0, 0.0]
-totw = [0.0, 0.0]
+totw = [0.0, 0.0, 0.0]
 for name, ci, co, h, k, s, p, d, cnt in shapes:
     x = torch.randn(B, ci, h, h, device="cuda")
     w = torch.randn(co, ci, k, k, device="cuda")
@@ -33,18 +34,24 @@ for name, ci, co, h, k, s, p, d, cnt in shapes:
     t2 = timeit(lambda: conv2d_weight(x, w.shape, dy, s, p, d), 10)
     tw = tg = 0.0
     if k == 3 and s == 1 and d == 1:
-        from spot_amd import ops
         tw = timeit(lambda: ops._winograd(x, w, co, False), 10)
         tg = timeit(lambda: ops._winograd(dy, w, ci, True), 10)
+        dwb = torch.empty_like(w)
+        wsb = torch.empty((lib.load().spot_conv3x3_winograd_wgrad_ws_floats(B, ci, co, h, h),), device="cuda")
+        tww = timeit(lambda: lib.call("spot_conv3x3_winograd_wgrad_f32", ops._p(x), ops._p(dy), ops._p(dwb), ops._p(wsb),
+                                      B, ci, co, h, h, 0, ops._st()), 10)
         totw[0] += tw * cnt
         totw[1] += tg * cnt
+        totw[2] += tww * cnt
     else:
+        tww = 0.0
+        totw[2] += t2 * cnt
         totw[0] += t0 * cnt
         totw[1] += t1 * cnt
     for i, t in enumerate((t0, t1, t2)):
         tot[i] += t * cnt
     print("%-24s x%d  fwd %7.1f us %6.1f TF | dgrad %7.1f us %6.1f TF | wgrad %7.1f us %6.1f TF" % (
         name, cnt, t0 * 1e6, fl / t0 / 1e12, t1 * 1e6, fl / t1 / 1e12 if t1 else 0, t2 * 1e6, fl / t2 / 1e12) +
-          (" | winograd fwd %7.1f us, dgrad %7.1f us" % (tw * 1e6, tg * 1e6) if tw else ""))
+          (" | winograd fwd %7.1f us, dgrad %7.1f us, wgrad %7.1f us" % (tw * 1e6, tg * 1e6, tww * 1e6) if tw else ""))
 print("per pass over both streams: fwd %.2f ms, dgrad %.2f ms, wgrad %.2f ms" % tuple(t * 1e3 for t in tot))
-print("with the Winograd path where it applies: fwd %.2f ms, dgrad %.2f ms" % tuple(t * 1e3 for t in totw))
+print("with the Winograd path where it applies: fwd %.2f ms, dgrad %.2f ms, wgrad %.2f ms" % tuple(t * 1e3 for t in totw))
