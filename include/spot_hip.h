@@ -174,9 +174,10 @@ typedef struct spot_gemm_desc {
 
 int spot_gemm_f32(const spot_gemm_desc* desc /* host */, hipStream_t stream);
 
-/* Bias-free 3x3 convolution, stride 1, padding 1, dilation 1, NCHW fp32 (conv2 of the ResNet bottlenecks that
- * neither stride nor dilate: ltr/models/backbone/resnet.py:79-81 with :61-62 defaults), by Winograd F(4x4, 3x3):
- * weight / input transforms, 36 batched GEMMs on the matrix cores, output transform.  H and W multiples of 4.
+/* Bias-free 3x3 convolution, stride 1, dilation d = 1 or 2 with padding d, NCHW fp32 (conv2 of the ResNet
+ * bottlenecks that do not stride: ltr/models/backbone/resnet.py:79-81; d = 2 in layer3's first block, :166), by
+ * Winograd F(4x4, 3x3): weight / input transforms, 36 batched GEMMs on the matrix cores, output transform.  A
+ * dilated convolution runs as d*d undilated ones on the polyphase sub-maps.  H and W multiples of 4*d.
  *   flip = 0: out[B,Cout,H,W] = conv2d(in[B,Cin,H,W], w[Cout,Cin,3,3])                      (forward)
  *   flip = 1: out[B,Cout,H,W] = conv_transpose2d(in[B,Cin,H,W], w[Cin,Cout,3,3])            (input gradient: in = dy,
  *             w = the forward weight as stored, Cin = its output channels, Cout = its input channels)
@@ -184,14 +185,14 @@ int spot_gemm_f32(const spot_gemm_desc* desc /* host */, hipStream_t stream);
  * convolution by fp32 rounding of the transforms (~1e-6 relative to the largest term). */
 long spot_conv3x3_winograd_ws_floats(int B, int Cin, int Cout, int H, int W);
 int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, int B, int Cin, int Cout, int H,
-                              int W, int flip, hipStream_t stream);
+                              int W, int dilation, int flip, hipStream_t stream);
 
 /* Weight gradient of the same convolution in the transformed domain: dw[Cout,Cin,3,3] (+)= G^T (sum over tiles of
  * (A dY A^T) (B^T d B)) G, the tile sum being 36 batched GEMMs.  x [B,Cin,H,W] is the forward input, dy [B,Cout,H,W]
  * the output gradient; accumulate = 1 adds into dw (a slice of a gradient buffer). */
 long spot_conv3x3_winograd_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W);
 int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout,
-                                    int H, int W, int accumulate, hipStream_t stream);
+                                    int H, int W, int dilation, int accumulate, hipStream_t stream);
 
 /* nn.Dropout on a [rows, cols] tensor (transt_fusion.py:124,130-131,178,182,191-196) with a counter-based
  * mask keep(seed, row, col): out = keep ? x/(1-p) : 0.  The same (seed, row, col) function is used by the GEMM

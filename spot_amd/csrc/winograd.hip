@@ -1,5 +1,6 @@
 // 3x3 stride-1 convolutions of the ResNet bottlenecks (ltr/models/backbone/resnet.py:79-81: conv2 of every
-// block that neither strides nor dilates) by Winograd F(4x4, 3x3) in fp32, forward and input gradient.
+// block that does not stride; dilation 1, or 2 as in layer3's first block, :61-62,166) by Winograd F(4x4, 3x3)
+// in fp32: forward, input gradient and weight gradient.
 //
 // A 4x4 output tile needs 36 multiplications per (input channel, output channel) pair instead of 144, and in
 // the transformed domain those are 36 independent GEMMs  M_xi[co][p] = sum_ci U_xi[co][ci] V_xi[ci][p]
@@ -78,26 +79,48 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     }
 }
 
+// Where tile p of channel c lives.  With dilation D the convolution splits into D*D independent undilated ones on
+// the polyphase sub-maps x[D*i + a][D*j + b] (padding D becomes padding 1 on each), so a "map" here is one
+// sub-map: Hs x Ws pixels, rs / D floats apart along rows / columns.
+template <int D>
+struct TileGeo {
+    const float* base;    // pixel (0, 0) of the tile's sub-map
+    int r0, c0, Hs, Ws;   // first output row / column of the tile within the sub-map
+    size_t rs;
+    __device__ __forceinline__ TileGeo(const float* x, int p, int c, int C, int H, int W) {
+        Hs = H / D; Ws = W / D;
+        const int TW = Ws >> 2, T = (Hs >> 2) * TW;
+        const int sub = p / T, t = p - sub * T, ty = t / TW, tx = t - ty * TW;
+        const int b = sub / (D * D), ph = sub - b * (D * D);
+        base = x + ((size_t)b * C + c) * H * W + (size_t)(ph / D) * W + (ph % D);
+        rs = (size_t)D * W;
+        r0 = 4 * ty; c0 = 4 * tx;
+    }
+};
+
 // V[xi][c][p] = (B^T d B)[xi], d = the 6x6 input patch of tile p (rows 4ty-1 .. 4ty+4, zero outside the map)
+template <int D>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int C, int H,
                                                          int W, int P) {
     const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
     if (p >= P) return;
-    const int TW = W >> 2, T = (H >> 2) * TW;
-    const int b = p / T, t = p - b * T, ty = t / TW, tx = t - ty * TW;
-    const float* xp = x + ((size_t)b * C + c) * H * W;
-    const int c0 = 4 * tx;
+    const TileGeo<D> g(x, p, c, C, H, W);
     float tmp[6][6];      // B^T d, built column by column after loading the patch rows
     float d[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const int r = 4 * ty - 1 + i;
-        if (r >= 0 && r < H) {
-            const float* rp = xp + (size_t)r * W + c0;
-            const float4 mid = *reinterpret_cast<const float4*>(rp);
-            d[i][0] = c0 > 0 ? rp[-1] : 0.f;
-            d[i][1] = mid.x; d[i][2] = mid.y; d[i][3] = mid.z; d[i][4] = mid.w;
-            d[i][5] = c0 + 4 < W ? rp[4] : 0.f;
+        const int r = g.r0 - 1 + i;
+        if (r >= 0 && r < g.Hs) {
+            const float* rp = g.base + (size_t)r * g.rs + (size_t)g.c0 * D;
+            if (D == 1) {
+                const float4 mid = *reinterpret_cast<const float4*>(rp);
+                d[i][1] = mid.x; d[i][2] = mid.y; d[i][3] = mid.z; d[i][4] = mid.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[i][1 + j] = rp[j * D];
+            }
+            d[i][0] = g.c0 > 0 ? rp[-D] : 0.f;
+            d[i][5] = g.c0 + 4 < g.Ws ? rp[4 * D] : 0.f;
         } else {
 #pragma unroll
             for (int j = 0; j < 6; ++j) d[i][j] = 0.f;
@@ -122,12 +145,12 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 }
 
 // y tile = A^T M A
+template <int D>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, float* __restrict__ y, int C, int H,
                                                           int W, int P) {
     const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
     if (p >= P) return;
-    const int TW = W >> 2, T = (H >> 2) * TW;
-    const int b = p / T, t = p - b * T, ty = t / TW, tx = t - ty * TW;
+    const TileGeo<D> g(y, p, c, C, H, W);
     const size_t plane = (size_t)C * P;
     const float* mp = Mb + (size_t)c * P + p;
     float tmp[4][6];
@@ -139,12 +162,17 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) tmp[i][j] = o[i];
     }
-    float* yp = y + ((size_t)b * C + c) * H * W + (size_t)(4 * ty) * W + 4 * tx;
+    float* yp = const_cast<float*>(g.base) + (size_t)g.r0 * g.rs + (size_t)g.c0 * D;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float o[4];
         at6(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], tmp[i][4], tmp[i][5], o);
-        *reinterpret_cast<float4*>(yp + (size_t)i * W) = make_float4(o[0], o[1], o[2], o[3]);
+        if (D == 1) {
+            *reinterpret_cast<float4*>(yp + (size_t)i * g.rs) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yp[(size_t)i * g.rs + j * D] = o[j];
+        }
     }
 }
 
@@ -160,16 +188,20 @@ __device__ __forceinline__ void a4(const float y0, const float y1, const float y
 }
 
 // dM[xi][c][p] = (A dY A^T)[xi], dY = the 4x4 output-gradient tile p of channel c
+template <int D>
 __global__ __launch_bounds__(256) void wino_outgrad_kernel(const float* __restrict__ dy, float* __restrict__ dM, int C,
                                                            int H, int W, int P) {
     const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
     if (p >= P) return;
-    const int TW = W >> 2, T = (H >> 2) * TW;
-    const int b = p / T, t = p - b * T, ty = t / TW, tx = t - ty * TW;
-    const float* yp = dy + ((size_t)b * C + c) * H * W + (size_t)(4 * ty) * W + 4 * tx;
+    const TileGeo<D> g(dy, p, c, C, H, W);
+    const float* yp = g.base + (size_t)g.r0 * g.rs + (size_t)g.c0 * D;
     float4 r[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(yp + (size_t)i * W);
+    for (int i = 0; i < 4; ++i) {
+        if (D == 1) r[i] = *reinterpret_cast<const float4*>(yp + (size_t)i * g.rs);
+        else r[i] = make_float4(yp[(size_t)i * g.rs], yp[(size_t)i * g.rs + D], yp[(size_t)i * g.rs + 2 * D],
+                                yp[(size_t)i * g.rs + 3 * D]);
+    }
     float tmp[6][4];
     {
         float o[6];
@@ -247,11 +279,19 @@ extern "C" long spot_conv3x3_winograd_ws_floats(int B, int Cin, int Cout, int H,
     return s.U + s.V + s.M;
 }
 
+#define WINO_LAUNCH(kernel, dil, grid, ...)                                   \
+    do {                                                                      \
+        if ((dil) == 1) kernel<1><<<grid, 256, 0, stream>>>(__VA_ARGS__);     \
+        else kernel<2><<<grid, 256, 0, stream>>>(__VA_ARGS__);                \
+    } while (0)
+
 extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, int B, int Cin, int Cout,
-                                         int H, int W, int flip, hipStream_t stream) {
+                                         int H, int W, int dilation, int flip, hipStream_t stream) {
     SPOT_CHECK_ARG(in && w && out && ws, "conv3x3_winograd: null pointer");
     SPOT_CHECK_ARG(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_winograd: bad shape");
-    SPOT_CHECK_ARG(H % 4 == 0 && W % 4 == 0, "conv3x3_winograd: H=%d, W=%d must be multiples of 4", H, W);
+    SPOT_CHECK_ARG(dilation == 1 || dilation == 2, "conv3x3_winograd: dilation=%d (1 or 2)", dilation);
+    SPOT_CHECK_ARG(H % (4 * dilation) == 0 && W % (4 * dilation) == 0,
+                   "conv3x3_winograd: H=%d, W=%d must be multiples of %d", H, W, 4 * dilation);
     SPOT_CHECK_ARG((((uintptr_t)in | (uintptr_t)out | (uintptr_t)ws) & 15) == 0, "conv3x3_winograd: buffers must be 16-byte aligned");
     const long Pl = (long)B * (H / 4) * (W / 4);
     SPOT_CHECK_ARG(Pl * (long)(Cin > Cout ? Cin : Cout) * XI < (1L << 40) && Pl < (1L << 31), "conv3x3_winograd: problem too large");
@@ -262,7 +302,7 @@ extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float*
     float* Mb = V + s.V;
     wino_weights_kernel<<<spot_ceil_div((long)Cout * Cin, 256), 256, 0, stream>>>(w, U, Cout, Cin, flip);
     SPOT_CHECK_LAUNCH("conv3x3_winograd(weights)");
-    wino_input_kernel<<<dim3(spot_ceil_div(P, 256), Cin), 256, 0, stream>>>(in, V, Cin, H, W, P);
+    WINO_LAUNCH(wino_input_kernel, dilation, dim3(spot_ceil_div(P, 256), Cin), in, V, Cin, H, W, P);
     SPOT_CHECK_LAUNCH("conv3x3_winograd(input)");
     spot_gemm_desc d = {};
     d.A = U; d.B = V; d.C = Mb;
@@ -273,7 +313,7 @@ extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float*
     d.splitk = 1; d.alpha = 1.f;
     const int rc = spot_gemm_f32(&d, stream);
     if (rc != SPOT_OK) return rc;
-    wino_output_kernel<<<dim3(spot_ceil_div(P, 256), Cout), 256, 0, stream>>>(Mb, out, Cout, H, W, P);
+    WINO_LAUNCH(wino_output_kernel, dilation, dim3(spot_ceil_div(P, 256), Cout), Mb, out, Cout, H, W, P);
     SPOT_CHECK_LAUNCH("conv3x3_winograd(output)");
     return SPOT_OK;
 }
@@ -283,10 +323,13 @@ extern "C" long spot_conv3x3_winograd_wgrad_ws_floats(int B, int Cin, int Cout, 
 }
 
 extern "C" int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int B, int Cin,
-                                               int Cout, int H, int W, int accumulate, hipStream_t stream) {
+                                               int Cout, int H, int W, int dilation, int accumulate,
+                                               hipStream_t stream) {
     SPOT_CHECK_ARG(x && dy && dw && ws, "conv3x3_winograd_wgrad: null pointer");
     SPOT_CHECK_ARG(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_winograd_wgrad: bad shape");
-    SPOT_CHECK_ARG(H % 4 == 0 && W % 4 == 0, "conv3x3_winograd_wgrad: H=%d, W=%d must be multiples of 4", H, W);
+    SPOT_CHECK_ARG(dilation == 1 || dilation == 2, "conv3x3_winograd_wgrad: dilation=%d (1 or 2)", dilation);
+    SPOT_CHECK_ARG(H % (4 * dilation) == 0 && W % (4 * dilation) == 0,
+                   "conv3x3_winograd_wgrad: H=%d, W=%d must be multiples of %d", H, W, 4 * dilation);
     SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15) == 0, "conv3x3_winograd_wgrad: buffers must be 16-byte aligned");
     const long Pl = (long)B * (H / 4) * (W / 4);
     SPOT_CHECK_ARG(Pl * (long)(Cin > Cout ? Cin : Cout) * XI < (1L << 40) && Pl < (1L << 31), "conv3x3_winograd_wgrad: problem too large");
@@ -295,9 +338,9 @@ extern "C" int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* dy, 
     float* dU = ws;
     float* V = dU + s.U;
     float* dM = V + s.V;
-    wino_input_kernel<<<dim3(spot_ceil_div(P, 256), Cin), 256, 0, stream>>>(x, V, Cin, H, W, P);
+    WINO_LAUNCH(wino_input_kernel, dilation, dim3(spot_ceil_div(P, 256), Cin), x, V, Cin, H, W, P);
     SPOT_CHECK_LAUNCH("conv3x3_winograd_wgrad(input)");
-    wino_outgrad_kernel<<<dim3(spot_ceil_div(P, 256), Cout), 256, 0, stream>>>(dy, dM, Cout, H, W, P);
+    WINO_LAUNCH(wino_outgrad_kernel, dilation, dim3(spot_ceil_div(P, 256), Cout), dy, dM, Cout, H, W, P);
     SPOT_CHECK_LAUNCH("conv3x3_winograd_wgrad(output gradient)");
     // dU[xi][co][ci] = sum_p dM[xi][co][p] V[xi][ci][p]: the tile index is the reduction; split it when the 36 output
     // matrices alone give too few workgroups

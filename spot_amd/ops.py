@@ -670,12 +670,13 @@ def conv1x1(x, conv):
 # ---------------------------------------------------------------------------
 # 3x3 convolutions of the ResNet bottleneck
 # ---------------------------------------------------------------------------
-def _winograd(inp, weight, Cout, flip):
+def _winograd(inp, weight, Cout, flip, dilation=1):
     B, Cin, H, W = inp.shape
     out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=inp.device)
     ws = torch.empty((lib.load().spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W),), dtype=torch.float32,
                      device=inp.device)
-    lib.call("spot_conv3x3_winograd_f32", _p(inp), _p(weight), _p(out), _p(ws), B, Cin, Cout, H, W, int(flip), _st())
+    lib.call("spot_conv3x3_winograd_f32", _p(inp), _p(weight), _p(out), _p(ws), B, Cin, Cout, H, W, int(dilation),
+             int(flip), _st())
     return out
 
 
@@ -685,23 +686,25 @@ class Conv3x3Fn(torch.autograd.Function):
     added straight into the flat gradient buffer), or by the convolution library with SPOT_WINOGRAD_WGRAD=0."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, dilation=1):
         x = _chk(x.contiguous())
         ctx.save_for_backward(x, weight)
         ctx.params = (weight,)
+        ctx.dilation = dilation
         if ctx.needs_input_grad[1] and _WINOGRAD_WGRAD:
             _sink_expect(weight)
-        return _winograd(x, weight, weight.shape[0], flip=False)
+        return _winograd(x, weight, weight.shape[0], False, dilation)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         (pw,) = ctx.params
         dy = dy.contiguous()
-        dx = _winograd(dy, weight, weight.shape[1], flip=True) if ctx.needs_input_grad[0] else None
+        dil = ctx.dilation
+        dx = _winograd(dy, weight, weight.shape[1], True, dil) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and not _WINOGRAD_WGRAD:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (dil, dil), (dil, dil), False, (0, 0), 1,
                                                      (False, True, False))[1]
         elif ctx.needs_input_grad[1]:
             B, Cin, H, W = x.shape
@@ -710,12 +713,12 @@ class Conv3x3Fn(torch.autograd.Function):
             dw = sk if sk is not None else torch.empty_like(weight)
             ws = torch.empty((lib.load().spot_conv3x3_winograd_wgrad_ws_floats(B, Cin, Cout, H, W),), dtype=torch.float32,
                              device=x.device)
-            lib.call("spot_conv3x3_winograd_wgrad_f32", _p(x), _p(dy), _p(dw), _p(ws), B, Cin, Cout, H, W,
+            lib.call("spot_conv3x3_winograd_wgrad_f32", _p(x), _p(dy), _p(dw), _p(ws), B, Cin, Cout, H, W, dil,
                      int(sk is not None), _st())
             if sk is not None:
                 dw = None
                 _sink_done(pw)
-        return dx, dw
+        return dx, dw, None
 
 
 _WINOGRAD_WGRAD = os.environ.get("SPOT_WINOGRAD_WGRAD", "1") == "1"
@@ -725,13 +728,15 @@ _WINOGRAD_MIN_TILES = int(os.environ.get("SPOT_WINOGRAD_MIN_TILES", "512"))   # 
 
 
 def conv3x3(x, conv):
-    """nn.Conv2d `conv` applied to x: the Winograd path for bias-free 3x3 / stride 1 / padding 1 / dilation 1
-    convolutions on maps whose sides are multiples of 4, the convolution library otherwise."""
+    """nn.Conv2d `conv` applied to x: the Winograd path for bias-free 3x3 / stride 1 convolutions with dilation d = 1
+    or 2 and padding d on maps whose sides are multiples of 4d, the convolution library otherwise."""
     B, _, H, W = x.shape
+    d = conv.dilation[0]
     if (_WINOGRAD_MIN_TILES >= 0 and x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
-            and H % 4 == 0 and W % 4 == 0 and B * (H // 4) * (W // 4) >= _WINOGRAD_MIN_TILES):
-        return Conv3x3Fn.apply(x, conv.weight)
+            and d in (1, 2) and conv.dilation == (d, d) and conv.padding == (d, d) and conv.groups == 1
+            and conv.bias is None and H % (4 * d) == 0 and W % (4 * d) == 0
+            and B * (H // 4) * (W // 4) >= _WINOGRAD_MIN_TILES):
+        return Conv3x3Fn.apply(x, conv.weight, d)
     return conv(x)
 
 

@@ -640,15 +640,16 @@ def test_conv1x1_as_gemm_vs_torch(ops, B, Ci, Co, H, W, stride):
     np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), wc.grad.numpy(), rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 8, 12, 8, 12), (3, 64, 64, 16, 16), (1, 5, 3, 4, 4), (2, 128, 96, 32, 32)])
-def test_conv3x3_winograd_vs_direct(ops, monkeypatch, B, Ci, Co, H, W):
+@pytest.mark.parametrize("B,Ci,Co,H,W,dil", [(2, 8, 12, 8, 12, 1), (3, 64, 64, 16, 16, 1), (1, 5, 3, 4, 4, 1),
+                                             (2, 128, 96, 32, 32, 1), (2, 8, 12, 8, 16, 2), (3, 64, 48, 32, 32, 2)])
+def test_conv3x3_winograd_vs_direct(ops, monkeypatch, B, Ci, Co, H, W, dil):
     """Forward, input gradient (Winograd) and weight gradient against torch's direct convolution in float64."""
     import torch.nn.functional as F
     monkeypatch.setattr(ops, "_WINOGRAD_MIN_TILES", 0)
     x = det_input("x", (B, Ci, H, W), 1, -1, 1)
     w = det_input("w", (Co, Ci, 3, 3), 2, -0.2, 0.2)
     dy = det_input("dy", (B, Co, H, W), 3, -1, 1)
-    conv = torch.nn.Conv2d(Ci, Co, 3, padding=1, bias=False).to(DEV)
+    conv = torch.nn.Conv2d(Ci, Co, 3, padding=dil, dilation=dil, bias=False).to(DEV)
     with torch.no_grad():
         conv.weight.copy_(G(w))
     xg = G(x).requires_grad_()
@@ -657,7 +658,7 @@ def test_conv3x3_winograd_vs_direct(ops, monkeypatch, B, Ci, Co, H, W):
     y.backward(G(dy))
     xr = T(x).double().requires_grad_()
     wr = T(w).double().requires_grad_()
-    yr = F.conv2d(xr, wr, None, 1, 1)
+    yr = F.conv2d(xr, wr, None, 1, dil, dil)
     yr.backward(T(dy).double())
     scale = float(yr.detach().abs().max())
     np.testing.assert_allclose(y.detach().cpu().double().numpy(), yr.detach().numpy(), rtol=0, atol=2e-5 * scale)
@@ -665,7 +666,7 @@ def test_conv3x3_winograd_vs_direct(ops, monkeypatch, B, Ci, Co, H, W):
                                atol=2e-5 * float(xr.grad.abs().max()))
     np.testing.assert_allclose(conv.weight.grad.cpu().double().numpy(), wr.grad.numpy(), rtol=0,
                                atol=1e-4 * float(wr.grad.abs().max()))
-    # strided / dilated / biased convolutions stay with the convolution library
-    other = torch.nn.Conv2d(Ci, Co, 3, padding=2, dilation=2, bias=False).to(DEV)
+    # strided / biased convolutions stay with the convolution library
+    other = torch.nn.Conv2d(Ci, Co, 3, padding=1, stride=2, bias=False).to(DEV)
     assert not type(ops.conv3x3(xg, other).grad_fn).__name__.startswith("Conv3x3Fn")
 

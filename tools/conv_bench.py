@@ -33,13 +33,13 @@ for name, ci, co, h, k, s, p, d, cnt in shapes:
     t1 = timeit(lambda: conv2d_input(x.shape, w, dy, s, p, d), 10) if ci > 3 else 0.0
     t2 = timeit(lambda: conv2d_weight(x, w.shape, dy, s, p, d), 10)
     tw = tg = 0.0
-    if k == 3 and s == 1 and d == 1:
-        tw = timeit(lambda: ops._winograd(x, w, co, False), 10)
-        tg = timeit(lambda: ops._winograd(dy, w, ci, True), 10)
+    if k == 3 and s == 1:
+        tw = timeit(lambda: ops._winograd(x, w, co, False, d), 10)
+        tg = timeit(lambda: ops._winograd(dy, w, ci, True, d), 10)
         dwb = torch.empty_like(w)
         wsb = torch.empty((lib.load().spot_conv3x3_winograd_wgrad_ws_floats(B, ci, co, h, h),), device="cuda")
         tww = timeit(lambda: lib.call("spot_conv3x3_winograd_wgrad_f32", ops._p(x), ops._p(dy), ops._p(dwb), ops._p(wsb),
-                                      B, ci, co, h, h, 0, ops._st()), 10)
+                                      B, ci, co, h, h, d, 0, ops._st()), 10)
         totw[0] += tw * cnt
         totw[1] += tg * cnt
         totw[2] += tww * cnt
