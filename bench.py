@@ -86,21 +86,26 @@ def build_job(args, rank):
     return S, trainer, data_sup, data_unsup, mid
 
 
-# timer key -> kernel symbol in the profiles (template arguments: A layout, B layout, aligned operands)
-KERNEL_SYMBOLS = {"gemm_nt": "gemm_kernel<1, 1, true>", "gemm_nn": "gemm_kernel<1, 0, true>",
-                  "gemm_tn": "gemm_kernel<0, 0, true>", "gemm_tt": "gemm_kernel<0, 1, true>",
+# timer key -> kernel symbol prefix in the profiles (template arguments: A layout, B layout, aligned operands, then
+# the workgroup tile and the row-sum flag, which the prefix leaves open)
+KERNEL_SYMBOLS = {"gemm_nt": "gemm_kernel<1, 1, true", "gemm_nn": "gemm_kernel<1, 0, true",
+                  "gemm_tn": "gemm_kernel<0, 0, true", "gemm_tt": "gemm_kernel<0, 1, true",
                   "mha_fwd": "mha_fwd_pp_kernel", "mha_bwd": "mha_bwd_kernel<false>"}
 
 
 def measured_traffic(key):
-    """HBM bytes per launch of the kernel class, from the committed counter passes over this same command
-    (profiles/r1_traffic.json, written by tools/collect_traffic.sh); None if no such measurement exists."""
+    """HBM bytes per launch of the kernel class (launch-weighted over its instantiations), from the committed
+    counter passes over this same command (profiles/r1_traffic.json, written by tools/collect_traffic.sh); None if
+    no such measurement exists."""
     symbol = KERNEL_SYMBOLS.get(key.split(" ")[0])
     path = os.path.join(ROOT, "profiles", "r1_traffic.json")
     if symbol is None or not os.path.exists(path):
         return None, symbol
-    entry = json.load(open(path))["kernels"].get(symbol)
-    return (round(entry["hbm_bytes_per_launch"]) if entry else None), symbol
+    rows = [v for k, v in json.load(open(path))["kernels"].items() if k.startswith(symbol)]
+    n = sum(r["launches"] for r in rows)
+    if n == 0:
+        return None, symbol
+    return round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n), symbol + ", ...>"
 
 
 def cpu_baseline(args):

@@ -4,8 +4,9 @@ Mirror of ltr/models/backbone/resnet.py:56-92,95-205 and
 ltr/models/backbone/transt_backbone.py:55-106 with identical state-dict keys
 (`backbone.0.body.conv1.weight`, `...layer3.5.bn3.running_var`, ...).
 
-The dense 3x3/1x1 convolutions of the ResNet run through PyTorch-ROCm (MIOpen) —
-the one part of the path that is not a hand-written kernel yet.  BatchNorm is
+The 1x1 convolutions are batched GEMMs of libspot_hip.so on the NCHW maps (ops.conv1x1), the
+stride-1 3x3 convolutions its Winograd F(4x4,3x3) path (ops.conv3x3); the 7x7 stem, the one
+stride-2 3x3 convolution and the max-pool stay with PyTorch-ROCm.  BatchNorm is
 fused with the ReLU / residual add that follow it (batchnorm.hip); everything
 downstream (projection, fusion, heads, decode, filter) is libspot_hip.so.
 The nn.BatchNorm2d modules remain as parameter/buffer holders so state-dict
