@@ -167,6 +167,7 @@ typedef struct spot_gemm_desc {
     float drop_p;        /* dropout after relu and before mask/residual: v = keep ? v/(1-p) : 0; 0 = off */
     unsigned drop_seed;  /* mask = f(drop_seed, global row z*M + m, column n): see spot_dropout_f32 */
     int tile;            /* workgroup tile: 0 = chosen from the problem shape, 64 = 64x64, 128 = 128x128 (same results) */
+    int rb_cols;         /* rowbias covers columns n < rb_cols only (0 = all N columns) */
     float* rowsum;       /* [M] or null: rowsum[m] += sum_k opA(A)[m][k], added atomically (clear it first).  Only with
                           * transA = transB = 1, batch = 1: the weight-gradient call dW = dY^T X, where this is the bias
                           * gradient sum_rows dY (the sum nn.Linear's backward takes separately) */

@@ -50,7 +50,8 @@ struct GemmArgs {
     float alpha;
     int accumulate;                   // C += result (plain read-modify-write; atomic when splitk > 1)
     const float* bias;                // [N] or null
-    const float* rowbias; int rb_rows; long ldrb;   // [rb_rows, N] indexed by m % rb_rows
+    const float* rowbias; int rb_rows; long ldrb;   // [rb_rows, rb_cols] indexed by m % rb_rows, columns n < rb_cols
+    int rb_cols;
     int relu;
     const float* mask; long ldmask;   // multiply by (mask[m][n] > 0)
     const float* residual; long ldres; long strideRes;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) 
                     const int row = i * (256 / BN) + tid / BN, m = mh + row;
                     if (m >= g.M) break;
                     float x = Cs[row * CPAD + col] * g.alpha + b1;
-                    if (rowbias) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + nn];
+                    if (rowbias && nn < g.rb_cols) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + nn];
                     if (res) x += res[(long)m * g.ldres + nn];
                     atomicAdd(C + (long)m * g.ldc + nn, x);
                 }
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) 
             v.x = v.x * g.alpha + bv.x; v.y = v.y * g.alpha + bv.y; v.z = v.z * g.alpha + bv.z; v.w = v.w * g.alpha + bv.w;
             float* cp = C + (long)m * g.ldc + n;
             if (full) {
-                if (rowbias) {
+                if (rowbias && n < g.rb_cols) {
                     const float4 r4 = *reinterpret_cast<const float4*>(rowbias + (long)(m % g.rb_rows) * g.ldrb + n);
                     v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                 }
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) 
                 for (int j = 0; j < 4; ++j) {
                     if (n + j >= g.N) break;
                     float x = vv[j];
-                    if (rowbias) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + n + j];
+                    if (rowbias && n + j < g.rb_cols) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + n + j];
                     if (g.relu) x = fmaxf(x, 0.f);
                     if (g.drop_thr)
                         x = spot_keep(spot_row_key(g.drop_seed, (unsigned)(zb * g.M + m)), n + j, g.drop_thr) ? x * g.drop_scale : 0.f;
@@ -432,6 +433,7 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
     a.accumulate = d->accumulate;
     a.bias = d->bias;
     a.rowbias = d->rowbias; a.rb_rows = d->rb_rows > 0 ? d->rb_rows : 1; a.ldrb = d->ldrb;
+    a.rb_cols = d->rb_cols > 0 ? d->rb_cols : d->N;
     a.relu = d->relu;
     a.mask = d->mask; a.ldmask = d->ldmask;
     a.residual = d->residual; a.ldres = d->ldres; a.strideRes = d->strideRes;
@@ -456,7 +458,7 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
     aligned = aligned && (ta ? (a.K % 4 == 0 && a.kseg % 4 == 0) : (a.M % 4 == 0));
     aligned = aligned && (tb ? (a.K % 4 == 0 && a.kseg % 4 == 0) : (a.N % 4 == 0));
     a.cvec = al(a.C) && a.ldc % 4 == 0 && a.strideC % 4 == 0 && a.N % 4 == 0 &&
-             (!a.bias || al(a.bias)) && (!a.rowbias || (al(a.rowbias) && a.ldrb % 4 == 0)) &&
+             (!a.bias || al(a.bias)) && (!a.rowbias || (al(a.rowbias) && a.ldrb % 4 == 0 && a.rb_cols % 4 == 0)) &&
              (!a.mask || (al(a.mask) && a.ldmask % 4 == 0)) &&
              (!a.residual || (al(a.residual) && a.ldres % 4 == 0 && a.strideRes % 4 == 0));
     // interior-tile loader: every k tile whole and inside one segment, element offsets within 32 bits

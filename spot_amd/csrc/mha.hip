@@ -430,8 +430,10 @@ constexpr int QP = DH + 4;   // padded LDS row
 
 __global__ __launch_bounds__(256) void mha_delta_kernel(const float* __restrict__ O, long ldo,
                                                         const float* __restrict__ dO, long lddo,
-                                                        float* __restrict__ delta, int Lq, int H, long total) {
-    // one 8-lane group per (b, q, head): 8 x float4 = 32 channels
+                                                        float* __restrict__ delta, float* __restrict__ dQ, long lddq,
+                                                        int Lq, int H, long total) {
+    // one 8-lane group per (b, q, head): 8 x float4 = 32 channels.  The same threads clear the head's dQ row,
+    // which the backward kernel accumulates into atomically.
     const long gidx = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
     const int part = threadIdx.x & 7;
     if (gidx >= total) return;
@@ -439,6 +441,7 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(const float* __restrict_
     const long bq = gidx / H;           // b*Lq + q
     const float4 a = *reinterpret_cast<const float4*>(O + bq * ldo + head * DH + 4 * part);
     const float4 g = *reinterpret_cast<const float4*>(dO + bq * lddo + head * DH + 4 * part);
+    *reinterpret_cast<float4*>(dQ + bq * lddq + head * DH + 4 * part) = make_float4(0.f, 0.f, 0.f, 0.f);
     float s = (a.x * g.x + a.y * g.y) + (a.z * g.z + a.w * g.w);
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
@@ -662,15 +665,10 @@ static int mha_bwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
     SPOT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mha_bwd: drop_p=%f outside [0,1)", drop_p);
     SPOT_CHECK_ARG(drop_p == 0.f || (Lq <= 65536 && Lk <= 65536), "mha_bwd: dropout needs Lq, Lk <= 65536");
     if (B == 0) return SPOT_OK;
-    // dQ is accumulated atomically: clear its [B*Lq, nhead*32] window first
-    hipError_t e = hipMemset2DAsync(dq, (size_t)lddq * sizeof(float), 0, (size_t)nhead * DH * sizeof(float),
-                                    (size_t)B * Lq, stream);
-    if (e != hipSuccess) {
-        spot_set_error("mha_bwd: clearing dq failed: %s", hipGetErrorString(e));
-        return SPOT_ERR_LAUNCH;
-    }
+    // dQ is accumulated atomically: the delta pass clears its [B*Lq, nhead*32] window on the way
     const long total = (long)B * Lq * nhead;
-    mha_delta_kernel<<<(int)((total * 8 + 255) / 256), 256, 0, stream>>>(out, ldo, d_out, lddo, delta_ws, Lq, nhead, total);
+    mha_delta_kernel<<<(int)((total * 8 + 255) / 256), 256, 0, stream>>>(out, ldo, d_out, lddo, delta_ws, dq, lddq, Lq,
+                                                                          nhead, total);
     SPOT_CHECK_LAUNCH("mha_bwd(delta)");
     dim3 grid((Lk + 127) / 128, nhead, B);
     if (bf16)

@@ -362,7 +362,7 @@ _GEMM_TILE = int(os.environ.get("SPOT_GEMM_TILE", "0"))   # 0: the library picks
 def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None, ldc=None, batch=1,
          strideA=0, strideB=0, strideC=0, kseg=0, segA=0, segB=0, splitk=1, alpha=1.0, accumulate=False,
          bias=None, rowbias=None, rb_rows=0, ldrb=0, relu=False, mask=None, ldmask=0, residual=None,
-         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0, tile=0, rowsum=None):
+         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0, tile=0, rowsum=None, rb_cols=0):
     """Raw access to spot_gemm_f32; tensors are only used for their base pointers."""
     d = GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
@@ -385,6 +385,7 @@ def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None,
     d.drop_p, d.drop_seed = drop_p, drop_seed
     d.tile = tile or _GEMM_TILE
     d.rowsum = rowsum.data_ptr() if rowsum is not None else None
+    d.rb_cols = rb_cols
     if TIMER is not None:
         key = "gemm_%s%s" % ("t" if transA else "n", "n" if transB else "t")
         if TIMER.shapes:
@@ -402,7 +403,7 @@ def _view2d(t):
 
 
 def linear_fwd(x2, W, bias=None, relu=False, residual=None, rowbias=None, out=None, drop_p=0.0, drop_seed=0):
-    """y[M,N] = x2[M,K] W[N,K]^T + bias (+ rowbias[m % R]) -> relu -> dropout -> + residual."""
+    """y[M,N] = x2[M,K] W[N,K]^T + bias (+ rowbias[m % R], over its own columns) -> relu -> dropout -> + residual."""
     M, K = x2.shape
     N = W.shape[0]
     if out is None:
@@ -410,6 +411,7 @@ def linear_fwd(x2, W, bias=None, relu=False, residual=None, rowbias=None, out=No
     gemm(x2, W, out, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=out.stride(0), bias=bias, relu=relu,
          rowbias=rowbias, rb_rows=rowbias.shape[0] if rowbias is not None else 0,
          ldrb=rowbias.stride(0) if rowbias is not None else 0,
+         rb_cols=rowbias.shape[1] if rowbias is not None else 0,
          residual=residual, ldres=residual.stride(0) if residual is not None else 0, drop_p=drop_p,
          drop_seed=drop_seed)
     return out
@@ -924,21 +926,17 @@ class MHAFn(torch.autograd.Function):
         xq2, xkv2 = _view2d(xq.contiguous()), _view2d(xkv.contiguous())
         dev = xq.device
         if self_attn:
-            R = pos_q.shape[0]
-            table = torch.empty((R, 3 * Cn), dtype=torch.float32, device=dev)
-            linear_fwd(pos_q, in_w[:2 * Cn], in_b[:2 * Cn], out=table[:, :2 * Cn])
-            table[:, 2 * Cn:] = in_b[2 * Cn:]
-            qkv = linear_fwd(xq2, in_w, None, rowbias=table)
+            # (x + pos) Wqk^T + b = x Wqk^T + b + pos Wqk^T: the last term is a [R, 2C] table over the q|k columns
+            table = linear_fwd(pos_q, in_w[:2 * Cn], None)
+            qkv = linear_fwd(xq2, in_w, in_b, rowbias=table)
             q, k, v = qkv, qkv[:, Cn:], qkv[:, 2 * Cn:]
             ldq = ldk = ldv = 3 * Cn
             kv = None
         else:
             tq = _pos_table(pos_q, in_w[:Cn], in_b[:Cn])
-            tk = torch.empty((pos_k.shape[0], 2 * Cn), dtype=torch.float32, device=dev)
-            linear_fwd(pos_k, in_w[Cn:2 * Cn], in_b[Cn:2 * Cn], out=tk[:, :Cn])
-            tk[:, Cn:] = in_b[2 * Cn:]
+            tk = linear_fwd(pos_k, in_w[Cn:2 * Cn], None)            # [Rk, C] table over the k columns of k|v
             qkv = linear_fwd(xq2, in_w[:Cn], None, rowbias=tq)
-            kv = linear_fwd(xkv2, in_w[Cn:], None, rowbias=tk)
+            kv = linear_fwd(xkv2, in_w[Cn:], in_b[Cn:], rowbias=tk)
             q, k, v = qkv, kv, kv[:, Cn:]
             ldq, ldk, ldv = Cn, 2 * Cn, 2 * Cn
         need_grad = any(ctx.needs_input_grad)
