@@ -140,8 +140,9 @@ int spot_groupdw_f32(const float* x11, const float* x12, const float* x21, const
  *   splitk > 1: K is split over splitk workgroups that add atomically into C (set accumulate = 1 and
  *             clear C first); not combinable with relu / mask.
  *   rowsum: see the field.
- * Epilogue order: v = alpha*acc + bias[n] + rowbias[(m % rb_rows)*ldrb + n]; relu; dropout(drop_p, drop_seed);
- *                 v = mask[m*ldmask+n] > 0 ? v : 0; v += residual[m*ldres + n]; C = v or C += v. */
+ * Epilogue order: v = alpha*acc + bias[n] + rowbias[(m % rb_rows)*ldrb + n]; inference BatchNorm over rows (bn_*);
+ *                 relu (relu = 1); dropout(drop_p, drop_seed); v = mask[m*ldmask+n] > 0 ? v : 0;
+ *                 v += residual[m*ldres + n]; relu (relu = 2); C = v or C += v. */
 typedef struct spot_gemm_desc {
     const float* A;
     const float* B;
@@ -168,6 +169,11 @@ typedef struct spot_gemm_desc {
     unsigned drop_seed;  /* mask = f(drop_seed, global row z*M + m, column n): see spot_dropout_f32 */
     int tile;            /* workgroup tile: 0 = chosen from the problem shape, 64 = 64x64, 128 = 128x128 (same results) */
     int rb_cols;         /* rowbias covers columns n < rb_cols only (0 = all N columns) */
+    const float* bn_gamma;  /* [M] each, or bn_gamma = null: inference-mode BatchNorm over the rows, applied after the */
+    const float* bn_beta;   /* bias terms: v = v*a + (beta[m] - mean[m]*a), a = gamma[m] / sqrt(var[m] + bn_eps)      */
+    const float* bn_mean;   /* (nn.BatchNorm2d in eval() behind a 1x1 convolution whose output channels are the rows: */
+    const float* bn_var;    /* ltr/models/backbone/resnet.py:77-92 as the tracker and an eval() teacher run it)       */
+    float bn_eps;
     float* rowsum;       /* [M] or null: rowsum[m] += sum_k opA(A)[m][k], added atomically (clear it first).  Only with
                           * transA = transB = 1, batch = 1: the weight-gradient call dW = dY^T X, where this is the bias
                           * gradient sum_rows dY (the sum nn.Linear's backward takes separately) */

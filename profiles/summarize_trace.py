@@ -6,7 +6,7 @@ algorithm search during the warm-up steps.  This script keeps only the dispatche
 kernel of step (last - N) and the decode kernel of the last step (N whole steps) and prints the same
 columns as the --stats summary.
 
-usage: summarize_trace.py <kernel_trace.csv> <n_steps> [out.csv] [--skip-last K]
+usage: summarize_trace.py <kernel_trace.csv> <n_steps> [out.csv] [--skip-last K] [--marker KERNEL_SUBSTRING]
 
 --skip-last K leaves out the last K steps (bench.py appends 1 + --exclusive-steps serialised steps after the
 timed region when kernel timing is on; pass K = 3 for the default command so the window is the timed region).
@@ -33,11 +33,16 @@ def main():
         i = argv.index("--skip-last")
         skip = int(argv[i + 1])
         del argv[i:i + 2]
+    marker = "decode_filter_kernel<true"
+    if "--marker" in argv:                       # substring of the kernel name that delimits a step / frame
+        i = argv.index("--marker")
+        marker = argv[i + 1]
+        del argv[i:i + 2]
     sys.argv = argv
     path, n = sys.argv[1], int(sys.argv[2])
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [int(r["Start_Timestamp"]) for r in rows if "decode_filter_kernel<true" in r["Kernel_Name"]]
+    marks = [int(r["Start_Timestamp"]) for r in rows if marker in r["Kernel_Name"]]
     assert len(marks) > n + skip, "need more than %d decode launches, found %d" % (n + skip, len(marks))
     t0, t1 = marks[-n - 1 - skip], marks[-1 - skip]
     agg = defaultdict(lambda: [0, 0, 10 ** 18, 0])

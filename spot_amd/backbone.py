@@ -44,11 +44,14 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        c1 = ops.conv1x1 if (OWN_CONV1X1 and x.is_cuda) else (lambda t, conv: conv(t))
-        out = ops.batch_norm_act(c1(x, self.conv1), self.bn1, relu=True)
+        if OWN_CONV1X1 and x.is_cuda:
+            cb = ops.conv1x1_bn_act
+        else:
+            cb = lambda t, conv, bn, relu=False, residual=None: ops.batch_norm_act(conv(t), bn, relu=relu, residual=residual)
+        out = cb(x, self.conv1, self.bn1, relu=True)
         out = ops.batch_norm_act(ops.conv3x3(out, self.conv2), self.bn2, relu=True)
-        residual = x if self.downsample is None else ops.batch_norm_act(c1(x, self.downsample[0]), self.downsample[1])
-        return ops.batch_norm_act(c1(out, self.conv3), self.bn3, relu=True, residual=residual)
+        residual = x if self.downsample is None else cb(x, self.downsample[0], self.downsample[1])
+        return cb(out, self.conv3, self.bn3, relu=True, residual=residual)
 
 
 class ResNet50Layer3(nn.Module):

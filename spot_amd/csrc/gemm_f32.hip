@@ -4,7 +4,8 @@
 //   nn.Linear / in-proj / out-proj / FFN / MLP heads / 1x1 input_proj
 //   (ltr/models/neck/transt_fusion.py:121-133,172-199; transt_model.py:47-56,296-310).
 //
-//   C[M,N] (+)= alpha * opA(A) * opB(B)  (+ bias[n]) (+ rowbias[m % rb_rows][n]) -> relu? -> (* mask>0)? (+ residual)
+//   C[M,N] (+)= alpha * opA(A) * opB(B)  (+ bias[n]) (+ rowbias[m % rb_rows][n]) (-> inference BatchNorm over rows m)
+//               -> relu? -> (* mask>0)? (+ residual) -> relu (relu = 2)?
 //
 // Operand layouts (row-major storage, leading dimension in elements):
 //   A: "MK" = A[m*lda + k]   or "KM" = A[k*lda + m]   (a transposed activation / NCHW feature map)
@@ -59,6 +60,9 @@ struct GemmArgs {
     int fast;                         // operands allow the unguarded interior-tile loader (see gemm_kernel)
     unsigned drop_thr, drop_seed; float drop_scale;   // dropout after relu, before residual (0 = off)
     float* rowsum;                    // [M] += sum_k opA(A)[m][k] (atomic), or null
+    // inference-mode BatchNorm over the rows (output channels of a 1x1 convolution), or bn_gamma = null:
+    // v = v * a + (beta[m] - mean[m] * a), a = gamma[m] / sqrt(var[m] + eps)
+    const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_var; float bn_eps;
 };
 
 template <int LAYOUT_KCONTIG, bool ALIGNED, int TS>
@@ -328,7 +332,11 @@ __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) 
                     const float4 r4 = *reinterpret_cast<const float4*>(rowbias + (long)(m % g.rb_rows) * g.ldrb + n);
                     v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                 }
-                if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (g.bn_gamma) {
+                    const float sc = g.bn_gamma[m] / sqrtf(g.bn_var[m] + g.bn_eps), sh = g.bn_beta[m] - g.bn_mean[m] * sc;
+                    v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+                }
+                if (g.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (g.drop_thr) {
                     const unsigned rk = spot_row_key(g.drop_seed, (unsigned)(zb * g.M + m));
                     v.x = spot_keep(rk, n, g.drop_thr) ? v.x * g.drop_scale : 0.f;
@@ -345,6 +353,7 @@ __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) 
                     const float4 r4 = *reinterpret_cast<const float4*>(res + (long)m * g.ldres + n);
                     v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                 }
+                if (g.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (g.accumulate) {
                     float4 o = *reinterpret_cast<float4*>(cp);
                     o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
@@ -359,11 +368,16 @@ __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) 
                     if (n + j >= g.N) break;
                     float x = vv[j];
                     if (rowbias && n + j < g.rb_cols) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + n + j];
-                    if (g.relu) x = fmaxf(x, 0.f);
+                    if (g.bn_gamma) {
+                        const float sc = g.bn_gamma[m] / sqrtf(g.bn_var[m] + g.bn_eps);
+                        x = fmaf(x, sc, g.bn_beta[m] - g.bn_mean[m] * sc);
+                    }
+                    if (g.relu == 1) x = fmaxf(x, 0.f);
                     if (g.drop_thr)
                         x = spot_keep(spot_row_key(g.drop_seed, (unsigned)(zb * g.M + m)), n + j, g.drop_thr) ? x * g.drop_scale : 0.f;
                     if (g.mask) x = g.mask[(long)m * g.ldmask + n + j] > 0.f ? x : 0.f;
                     if (res) x += res[(long)m * g.ldres + n + j];
+                    if (g.relu == 2) x = fmaxf(x, 0.f);
                     if (g.accumulate) cp[j] += x;
                     else cp[j] = x;
                 }
@@ -438,6 +452,9 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
     a.mask = d->mask; a.ldmask = d->ldmask;
     a.residual = d->residual; a.ldres = d->ldres; a.strideRes = d->strideRes;
     a.rowsum = d->rowsum;
+    a.bn_gamma = d->bn_gamma; a.bn_beta = d->bn_beta; a.bn_mean = d->bn_mean; a.bn_var = d->bn_var; a.bn_eps = d->bn_eps;
+    SPOT_CHECK_ARG(!a.bn_gamma || (a.bn_beta && a.bn_mean && a.bn_var), "gemm: bn_gamma needs bn_beta, bn_mean and bn_var");
+    SPOT_CHECK_ARG(a.relu >= 0 && a.relu <= 2, "gemm: relu=%d (0 off, 1 before the residual, 2 after it)", a.relu);
     SPOT_CHECK_ARG(!a.rowsum || (d->transA && d->transB && d->batch == 1),
                    "gemm: rowsum is for the weight-gradient layout (transA = transB = 1, batch = 1)");
     SPOT_CHECK_ARG(a.kseg % BK == 0 || a.kseg >= a.K, "gemm: kseg=%d must be a multiple of %d", a.kseg, BK);
@@ -447,7 +464,8 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
     a.drop_seed = d->drop_seed;
     a.drop_scale = 1.f / (1.f - d->drop_p);
     if (a.splitk > 1) {
-        SPOT_CHECK_ARG(!a.relu && !a.mask && !a.drop_thr, "gemm: split-K cannot be combined with relu/mask/dropout epilogues");
+        SPOT_CHECK_ARG(!a.relu && !a.mask && !a.drop_thr && !a.bn_gamma,
+                       "gemm: split-K cannot be combined with relu/mask/dropout/BatchNorm epilogues");
         SPOT_CHECK_ARG(a.accumulate, "gemm: split-K accumulates atomically into C; zero C and set accumulate=1");
     }
     const int ta = d->transA ? 0 : 1, tb = d->transB ? 0 : 1;   // template arg 1 = k-contiguous

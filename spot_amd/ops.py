@@ -362,7 +362,7 @@ _GEMM_TILE = int(os.environ.get("SPOT_GEMM_TILE", "0"))   # 0: the library picks
 def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None, ldc=None, batch=1,
          strideA=0, strideB=0, strideC=0, kseg=0, segA=0, segB=0, splitk=1, alpha=1.0, accumulate=False,
          bias=None, rowbias=None, rb_rows=0, ldrb=0, relu=False, mask=None, ldmask=0, residual=None,
-         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0, tile=0, rowsum=None, rb_cols=0):
+         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0, tile=0, rowsum=None, rb_cols=0, bn=None):
     """Raw access to spot_gemm_f32; tensors are only used for their base pointers."""
     d = GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
@@ -386,6 +386,9 @@ def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None,
     d.tile = tile or _GEMM_TILE
     d.rowsum = rowsum.data_ptr() if rowsum is not None else None
     d.rb_cols = rb_cols
+    if bn is not None:          # (gamma, beta, running_mean, running_var, eps): inference BatchNorm over the rows
+        d.bn_gamma, d.bn_beta, d.bn_mean, d.bn_var = (t.data_ptr() for t in bn[:4])
+        d.bn_eps = float(bn[4])
     if TIMER is not None:
         key = "gemm_%s%s" % ("t" if transA else "n", "n" if transB else "t")
         if TIMER.shapes:
@@ -667,6 +670,33 @@ def conv1x1(x, conv):
     if x.shape[2] * x.shape[3] % 32 != 0:       # the batch-summed weight gradient walks K in whole 32-wide tiles per clip
         return torch.nn.functional.conv2d(x, conv.weight, None)
     return Conv1x1Fn.apply(x, conv.weight)
+
+
+def conv1x1_bn_act(x, conv, bn, relu=False, residual=None):
+    """[relu](bn(conv(x)) [+ residual]) for a bias-free 1x1 convolution.  With `bn` in inference mode (and no
+    gradient wanted) the normalisation is a per-output-channel affine map and rides in the GEMM's epilogue together
+    with the residual add and the ReLU: one launch, the map is written once.  Otherwise conv1x1 -> batch_norm_act."""
+    fold = (not bn.training and bn.track_running_stats and x.is_cuda and not torch.is_grad_enabled()
+            and conv.kernel_size == (1, 1) and conv.bias is None and conv.groups == 1 and conv.padding == (0, 0))
+    xs = x
+    if fold:
+        if conv.stride != (1, 1):
+            xs = x[:, :, ::conv.stride[0], ::conv.stride[1]]
+        xs = _chk(xs.contiguous())
+        B, Ci, H, W = xs.shape
+        Co, HW = conv.weight.shape[0], H * W
+        fold = HW % 4 == 0
+    if not fold:
+        return batch_norm_act(conv1x1(x, conv), bn, relu=relu, residual=residual)
+    x = xs
+    if residual is not None:
+        residual = _chk(residual.contiguous())
+    y = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+    gemm(conv.weight.view(Co, Ci), x, y, Co, HW, Ci, transB=True, lda=Ci, ldb=HW, ldc=HW, batch=B, strideB=Ci * HW,
+         strideC=Co * HW, bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps), residual=residual,
+         ldres=HW, strideRes=Co * HW,
+         relu=(2 if residual is not None else 1) if relu else 0)
+    return y
 
 
 # ---------------------------------------------------------------------------

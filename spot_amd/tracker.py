@@ -74,12 +74,16 @@ class TransT_Tracker(object):
         self.instance_size = instance_size
         self.mean = [0.485, 0.456, 0.406]
         self.std = [0.229, 0.224, 0.225]
-        # A frame is ~700 kernel launches at batch 1.  Optionally (use_graph=True or SPOT_TRACKER_GRAPH=1), from
-        # the third frame of a sequence on the whole device pipeline (normalise, backbone, fusion, heads, decode)
-        # replays as one captured HIP graph; frames 1-2 run eagerly and warm the convolution library's algorithm
-        # choice.  Measured on MI355X the frame time is the same either way (8.5-8.7 ms: the host already runs
-        # ahead of the GPU, whose ~700 small kernels take that long back to back), so it is off by default.
-        self.use_graph = (os.environ.get("SPOT_TRACKER_GRAPH", "0") == "1") if use_graph is None else bool(use_graph)
+        # A frame is ~250 kernel launches at batch 1 that keep the GPU busy for 3.2 ms, while enqueueing them from
+        # Python takes 8 ms: the eager frame is host-bound.  From the third frame of a sequence on, the whole device
+        # pipeline (normalise, backbone, fusion, heads, decode) therefore replays as one captured HIP graph (frames
+        # 1-2 run eagerly and warm the convolution library's algorithm choice): 8.2 -> 6.5 ms per frame on MI355X.
+        # use_graph=False or SPOT_TRACKER_GRAPH=0 keeps every frame eager.  A replayed graph repeats exactly the
+        # device work of the captured frame, so by default only this package's own network holder is trusted to be
+        # a pure device function of the crop; any other `net` object runs eagerly unless use_graph=True is passed.
+        if use_graph is None:
+            use_graph = os.environ.get("SPOT_TRACKER_GRAPH", "1") == "1" and isinstance(net, NetWithBackbone)
+        self.use_graph = bool(use_graph)
         self._graph = None
         self._eager_frames = 0
 

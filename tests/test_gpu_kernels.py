@@ -670,3 +670,35 @@ def test_conv3x3_winograd_vs_direct(ops, monkeypatch, B, Ci, Co, H, W, dil):
     other = torch.nn.Conv2d(Ci, Co, 3, padding=1, stride=2, bias=False).to(DEV)
     assert not type(ops.conv3x3(xg, other).grad_fn).__name__.startswith("Conv3x3Fn")
 
+
+@pytest.mark.parametrize("stride,with_res", [(1, False), (1, True), (2, False)])
+def test_conv1x1_with_folded_inference_batchnorm(ops, stride, with_res):
+    """eval()-mode BatchNorm behind a 1x1 convolution rides in the GEMM epilogue (with the residual add and the ReLU
+    after it): same result as convolution -> nn.BatchNorm2d.eval() -> (+ residual) -> relu in float64."""
+    B, Ci, Co, H, W = 3, 48, 80, 16, 24
+    x = det_input("x", (B, Ci, H, W), 1, -1, 1)
+    conv = torch.nn.Conv2d(Ci, Co, 1, stride=stride, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(Co).to(DEV).eval()
+    with torch.no_grad():
+        conv.weight.copy_(G(det_input("w", (Co, Ci, 1, 1), 2, -0.3, 0.3)))
+        bn.weight.copy_(G(det_input("g", (Co,), 3, 0.5, 1.5)))
+        bn.bias.copy_(G(det_input("b", (Co,), 4, -0.5, 0.5)))
+        bn.running_mean.copy_(G(det_input("m", (Co,), 5, -0.5, 0.5)))
+        bn.running_var.copy_(G(det_input("v", (Co,), 6, 0.5, 2.0)))
+    res = det_input("r", (B, Co, H // stride, W // stride), 7, -1, 1) if with_res else None
+    with torch.no_grad():
+        y = ops.conv1x1_bn_act(G(x), conv, bn, relu=True, residual=G(res) if with_res else None)
+        two_pass = ops.batch_norm_act(ops.conv1x1(G(x), conv), bn, relu=True, residual=G(res) if with_res else None)
+    ref = torch.nn.functional.conv2d(T(x).double(), conv.weight.detach().cpu().double(), None, stride)
+    a = bn.weight.detach().cpu().double() / torch.sqrt(bn.running_var.cpu().double() + bn.eps)
+    ref = ref * a.view(1, -1, 1, 1) + (bn.bias.detach().cpu().double() - bn.running_mean.cpu().double() * a).view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + T(res).double()
+    ref = torch.relu(ref)
+    np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(y, two_pass)          # the fused epilogue repeats the two-pass arithmetic exactly
+    # in training mode (or with gradients wanted) the same call is convolution -> batch-statistics BatchNorm
+    bn.train()
+    yt = ops.conv1x1_bn_act(G(x).requires_grad_(), conv, bn, relu=True, residual=G(res) if with_res else None)
+    assert yt.requires_grad
+

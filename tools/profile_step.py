@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--sup", type=int, default=8)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--cprofile", action="store_true")
+    ap.add_argument("--attention", default="f32")
     args = ap.parse_args()
     from spot_amd import lib
     from spot_amd.tensordict import TensorDict
