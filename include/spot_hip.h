@@ -201,6 +201,15 @@ long spot_conv3x3_winograd_wgrad_ws_floats(int B, int Cin, int Cout, int H, int 
 int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout,
                                     int H, int W, int dilation, int accumulate, hipStream_t stream);
 
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet stem (ltr/models/backbone/resnet.py:113,199) on
+ * `planes` = B*C maps of H x W (H even, W a multiple of 8).  winner [planes, H/2, W/2] (or null in inference)
+ * records which of the nine window positions held the maximum (the first one in row-major order on ties, as
+ * ATen); the backward gathers dy through it: dx[planes, H, W] is written once, no atomics. */
+int spot_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* winner, long planes, int H, int W,
+                              hipStream_t stream);
+int spot_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* winner, float* dx, long planes, int H, int W,
+                              hipStream_t stream);
+
 /* nn.Dropout on a [rows, cols] tensor (transt_fusion.py:124,130-131,178,182,191-196) with a counter-based
  * mask keep(seed, row, col): out = keep ? x/(1-p) : 0.  The same (seed, row, col) function is used by the GEMM
  * epilogue, so the backward pass re-applies a forward mask by calling this on the incoming gradient. */

@@ -89,7 +89,7 @@ class ResNet50Layer3(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(ops.batch_norm_act(self.conv1(x), self.bn1, relu=True))
+        x = ops.max_pool_3x3_s2(ops.batch_norm_act(self.conv1(x), self.bn1, relu=True), self.maxpool)
         return self.layer3(self.layer2(self.layer1(x)))
 
 

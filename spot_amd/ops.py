@@ -699,6 +699,43 @@ def conv1x1_bn_act(x, conv, bn, relu=False, residual=None):
     return y
 
 
+class MaxPool3x3s2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(3, stride=2, padding=1) (resnet.py:113,199): one byte per output remembers the winning window
+    position, the backward gathers through it."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x.contiguous())
+        B, Cn, H, W = x.shape
+        y = torch.empty((B, Cn, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        win = torch.empty((B, Cn, H // 2, W // 2), dtype=torch.uint8, device=x.device) if ctx.needs_input_grad[0] else None
+        lib.call("spot_maxpool3x3s2_fwd_f32", _p(x), _p(y), _p(win), B * Cn, H, W, _st())
+        ctx.save_for_backward(win)
+        ctx.shape = (B, Cn, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (win,) = ctx.saved_tensors
+        B, Cn, H, W = ctx.shape
+        dx = torch.empty((B, Cn, H, W), dtype=torch.float32, device=dy.device)
+        lib.call("spot_maxpool3x3s2_bwd_f32", _p(dy.contiguous()), _p(win), _p(dx), B * Cn, H, W, _st())
+        return dx
+
+
+def max_pool_3x3_s2(x, pool):
+    """nn.MaxPool2d `pool` applied to x: this library's kernel for the stem's 3x3 / stride 2 / padding 1 pool on
+    maps with even height and a width that is a multiple of 8, the module itself otherwise."""
+    ks = pool.kernel_size if isinstance(pool.kernel_size, tuple) else (pool.kernel_size,) * 2
+    st = pool.stride if isinstance(pool.stride, tuple) else (pool.stride,) * 2
+    pd = pool.padding if isinstance(pool.padding, tuple) else (pool.padding,) * 2
+    dl = pool.dilation if isinstance(pool.dilation, tuple) else (pool.dilation,) * 2
+    if (x.is_cuda and ks == (3, 3) and st == (2, 2) and pd == (1, 1) and dl == (1, 1) and not pool.ceil_mode
+            and not pool.return_indices and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0 and x.dtype == torch.float32):
+        return MaxPool3x3s2Fn.apply(x)
+    return pool(x)
+
+
 # ---------------------------------------------------------------------------
 # 3x3 convolutions of the ResNet bottleneck
 # ---------------------------------------------------------------------------

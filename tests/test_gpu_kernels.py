@@ -702,3 +702,25 @@ def test_conv1x1_with_folded_inference_batchnorm(ops, stride, with_res):
     yt = ops.conv1x1_bn_act(G(x).requires_grad_(), conv, bn, relu=True, residual=G(res) if with_res else None)
     assert yt.requires_grad
 
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 3, 8, 16), (3, 64, 128, 128), (1, 5, 6, 8)])
+def test_maxpool3x3s2_vs_torch(ops, B, C, H, W):
+    """Stem max-pool: values, tie-breaking and gradient equal nn.MaxPool2d(3, 2, 1) exactly."""
+    pool = torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+    x = det_input("x", (B, C, H, W), 1, -1, 1)
+    xt = T(x).clone()
+    xt[:, :, ::3, ::2] = 0.25                      # plateaus: ties inside many windows
+    xt[0, 0, :4, :8] = -3.0                        # a constant block at the padded corner
+    dy = det_input("dy", (B, C, H // 2, W // 2), 2, -1, 1)
+    xg = xt.to(DEV).requires_grad_()
+    y = ops.max_pool_3x3_s2(xg, pool)
+    assert type(y.grad_fn).__name__.startswith("MaxPool3x3s2Fn")
+    y.backward(G(dy))
+    xr = xt.clone().requires_grad_()
+    yr = pool(xr)
+    yr.backward(T(dy))
+    assert torch.equal(y.detach().cpu(), yr.detach())
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=0, atol=1e-6)   # <= 4 addends, order free
+    with torch.no_grad():
+        assert torch.equal(ops.max_pool_3x3_s2(xt.to(DEV), pool).cpu(), yr.detach())
+
