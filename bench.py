@@ -45,16 +45,18 @@ def build_job(args, rank):
 
     if os.environ.get("SPOT_CUDNN_BENCH", "0") == "1":
         torch.backends.cudnn.benchmark = True
-    # the reference's training configuration: dropout 0.1, brightness jitter 0.2 (spot_transt_003.py:80,85)
+    # the reference's training configuration: dropout 0.1; in-network augmentation with brightness jitter 0.2,
+    # grey-scale 0.05, rotation +-10 degrees, left/right flip 0.35, up/down flip 0.10 (spot_transt_003.py:45,80,85)
     S = Settings(device="cuda", dropout=args.dropout, batch_size_sup=args.sup, batch_size_unsup=args.clips)
-    S.aug_settings["jitter"] = 0.2
+    S.aug_settings.update(gray=0.05, jitter=0.2, angle=10, lr_f_prob=0.35, ud_f_prob=0.10)
+    S.strong_augmentation_tag = True
     S.attention_dtype = args.attention
     ops_seed = 1000 + rank
     from spot_amd import ops as _ops
     _ops.manual_seed(ops_seed)
     torch.manual_seed(ops_seed)
     stu = det_fill_(transt_resnet50(S), 0).cuda()
-    tea = det_fill_(transt_resnet50(S), 0).cuda()
+    tea = det_fill_(transt_resnet50(S, network="teacher"), 0).cuda()
     if os.environ.get("SPOT_CHANNELS_LAST", "0") == "1":
         stu.backbone.to(memory_format=torch.channels_last)
         tea.backbone.to(memory_format=torch.channels_last)
@@ -270,7 +272,8 @@ def main():
             "config": {"workload": "cfg2: %d clips x 3 frames per GPU per step; teacher pseudo-label + decode + "
                                    "filter + compaction + student fwd/bwd/AdamW on %d labelled + %d pseudo-labelled "
                                    "pairs (TransT ResNet-50, 128^2 template / 256^2 search, fp32%s, student dropout %g, "
-                                   "brightness jitter 0.2; the teacher stays in the module-default train() mode as in the "
+                                   "in-network augmentation as spot_transt_003.py: brightness jitter 0.2, grey-scale "
+                                   "0.05, rotation 10 deg + flips 0.35/0.10 on the pseudo-labelled pairs; the teacher stays in the module-default train() mode as in the "
                                    "reference, whose actor only toggles the student: batch-statistics BatchNorm and "
                                    "dropout are active in the pseudo-labelling pass too)"
                                    % (args.clips, args.sup, args.clips, "" if args.attention == "f32" else

@@ -210,6 +210,24 @@ int spot_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* winner, l
 int spot_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* winner, float* dx, long planes, int H, int W,
                               hipStream_t stream);
 
+/* ---- In-network strong augmentation of a crop batch (ltr/models/pre_input/transforms_in_net.py), NCHW fp32.
+ * EllipseRotationAffine.forward's image part (:168-178 with :240-331): for samples with apply[b] != 0, a left/right
+ * flip (lr_flip[b]) followed by a rotation by the integer angle (int)angle[b] degrees about the crop centre, nearest
+ * sampling, pixels from outside replaced by fill[b][c]; other samples are copied.  theta_table [721][6]: the inverse
+ * affine matrices of the integer angles -360..360 in centred pixel coordinates (host, double precision, as the
+ * reference's _get_inverse_affine_matrix(center=[0.5, 0.5], angle=-a, ...) computes them).  out != in. */
+int spot_rotate_flip_nearest_f32(const float* in, float* out, const float* theta_table, const float* angle,
+                                 const unsigned char* lr_flip, const unsigned char* apply, const float* fill, int B, int C,
+                                 int H, int W, hipStream_t stream);
+/* Its box part (:180-214): xywh boxes [B,4] follow as the bounding boxes of their inscribed ellipses (360 sample
+ * points) after the flip and the rotation by angle[b] degrees about (W/2, H/2); samples with apply[b] == 0 keep their
+ * box; all outputs are clamped at 0. */
+int spot_ellipse_rotate_boxes_f32(const float* bbox, const float* angle, const unsigned char* lr_flip,
+                                  const unsigned char* apply, float* out, int B, int W, int H, hipStream_t stream);
+/* x[p][:] *= scale[p] for planes p of HW floats (HW a multiple of 4), in place: the per-channel weighting of
+ * GrayScale.forward (:384-396) with scale = colour weight or 1 per (sample, channel). */
+int spot_channel_scale_f32(float* x, const float* scale, long planes, int HW, hipStream_t stream);
+
 /* nn.Dropout on a [rows, cols] tensor (transt_fusion.py:124,130-131,178,182,191-196) with a counter-based
  * mask keep(seed, row, col): out = keep ? x/(1-p) : 0.  The same (seed, row, col) function is used by the GEMM
  * epilogue, so the backward pass re-applies a forward mask by calling this on the incoming gradient. */

@@ -465,3 +465,79 @@ def tracker_post(pred_logits, pred_boxes, window, window_penalty, center_pos, si
     height = max(10, min(bbox[3], H))
     return ([cx - width / 2, cy - height / 2, width, height], pscore,
             np.array([cx, cy]), np.array([width, height]), s_x)
+
+
+# --------------------------------------------------------------------------
+# in-network augmentation (ltr/models/pre_input/transforms_in_net.py:121-398)
+# --------------------------------------------------------------------------
+def gray_scale(image_groups, avg_groups, gray_tag):
+    """GrayScale.forward (:378-398) for given draws: tagged samples get their channels weighted by
+    0.2989 / 0.5870 / 0.1140 (not summed) and their fill colour replaced by its weighted sum."""
+    w = torch.tensor([0.2989, 0.5870, 0.1140]).float()
+    imgs = [g.clone() for g in image_groups]
+    avgs = [a.clone().float() for a in avg_groups]
+    for i in range(imgs[0].shape[0]):
+        if gray_tag[i]:
+            for g in range(len(imgs)):
+                imgs[g][i].mul_(w[:, None, None])
+                c = avgs[g][i][0] * w[0] + avgs[g][i][1] * w[1] + avgs[g][i][2] * w[2]
+                avgs[g][i] = torch.stack([c, c, c])
+    return imgs, avgs
+
+
+def _inverse_rotation_matrix(angle_deg):
+    """_get_inverse_affine_matrix (:247-275) for center (0.5, 0.5), no translation, scale 1, no shear."""
+    rot = math.radians(angle_deg)
+    a, b, c, d = math.cos(rot), -math.sin(rot), math.sin(rot), math.cos(rot)
+    m = [d, -b, 0.0, -c, a, 0.0]
+    m[2] += m[0] * -0.5 + m[1] * -0.5
+    m[5] += m[3] * -0.5 + m[4] * -0.5
+    m[2] += 0.5
+    m[5] += 0.5
+    return m
+
+
+def _rotate_nearest(img, angle_deg, fill):
+    """affine() + _apply_grid_transform() (:277-331): centred base grid, theta rescaled to [-1, 1], nearest
+    grid_sample with zero padding, uncovered pixels (a ones channel sampled below 0.5) take `fill`."""
+    Cn, H, W = img.shape
+    theta = torch.tensor(_inverse_rotation_matrix(-angle_deg), dtype=torch.float32).reshape(1, 2, 3)
+    base = torch.empty(1, H, W, 3, dtype=torch.float32)
+    base[..., 0].copy_(torch.linspace(-W * 0.5 + 0.5, W * 0.5 + 0.5 - 1, steps=W))
+    base[..., 1].copy_(torch.linspace(-H * 0.5 + 0.5, H * 0.5 + 0.5 - 1, steps=H).unsqueeze_(-1))
+    base[..., 2].fill_(1)
+    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * W, 0.5 * H], dtype=torch.float32)
+    grid = base.view(1, H * W, 3).bmm(rescaled).view(1, H, W, 2)
+    x = torch.cat((img[None], torch.ones((1, 1, H, W), dtype=img.dtype)), dim=1)
+    x = F.grid_sample(x, grid, mode="nearest", padding_mode="zeros", align_corners=False)
+    covered, x = x[:, -1:], x[:, :-1]
+    fill_img = fill.to(img.dtype).view(1, Cn, 1, 1).expand_as(x)
+    return torch.where(covered.expand_as(x) < 0.5, fill_img, x)[0]
+
+
+def ellipse_rotation_affine(image, bbox, avg, mask, angle, lr_flip_tag):
+    """EllipseRotationAffine.forward (:150-216) for given draws (angle [B] float degrees incl. the 180 of an
+    up/down flip, lr_flip_tag [B] bool).  Returns (images, xywh boxes)."""
+    B, Cn, H, W = image.shape
+    out = image.clone()
+    for i in range(B):
+        if mask[i]:
+            src = out[i].flip((2,)) if lr_flip_tag[i] else out[i]
+            out[i] = _rotate_nearest(src, int(angle[i]), avg[i])
+    rwrh = 1 / 2 * bbox[:, 2:]
+    cxcy = bbox[:, :2] + rwrh
+    cxcy[:, 0] = torch.where(lr_flip_tag, (W - 1) - cxcy[:, 0], cxcy[:, 0])
+    a = torch.arange(0, 360, 1) * (math.pi / 180)
+    xs = rwrh[:, 0][:, None] * torch.sin(a).expand([B, 360]) + cxcy[:, 0][:, None]
+    ys = rwrh[:, 1][:, None] * torch.cos(a).expand([B, 360]) + cxcy[:, 1][:, None]
+    rad = angle * (math.pi / 180)
+    alpha, beta = torch.cos(rad), torch.sin(rad)
+    x0, y0 = W * 0.5, H * 0.5
+    M = torch.zeros(B, 2, 3)
+    M[:, 0, 0], M[:, 0, 1], M[:, 0, 2] = alpha, beta, (1. - alpha) * x0 - beta * y0
+    M[:, 1, 0], M[:, 1, 1], M[:, 1, 2] = -beta, alpha, beta * x0 + (1. - alpha) * y0
+    pts = torch.cat([xs.unsqueeze(1), ys.unsqueeze(1), torch.ones(xs.shape).unsqueeze(1)], dim=1).float()
+    tr = torch.bmm(M, pts)
+    mx, mn = tr.max(dim=2).values, tr.min(dim=2).values
+    new = torch.stack([mn[:, 0], mn[:, 1], mx[:, 0] - mn[:, 0], mx[:, 1] - mn[:, 1]], dim=1)
+    return out, torch.clamp_min(torch.where(mask[:, None], new, bbox), min=0.0)

@@ -63,6 +63,9 @@ SIGNATURES = {
     "spot_adamw_f32": [vp, vp, vp, vp, vp, i32, vp, vp],
     "spot_gemm_f32": [C.POINTER(GemmDesc), vp],
     "spot_colsum_f32": [vp, i64, vp, i64, i32, vp],
+    "spot_rotate_flip_nearest_f32": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "spot_ellipse_rotate_boxes_f32": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "spot_channel_scale_f32": [vp, vp, i64, i32, vp],
     "spot_maxpool3x3s2_fwd_f32": [vp, vp, vp, i64, i32, i32, vp],
     "spot_maxpool3x3s2_bwd_f32": [vp, vp, vp, i64, i32, i32, vp],
     "spot_conv3x3_winograd_f32": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],

@@ -47,6 +47,7 @@ class LTRSparseTrainer:
         self.skipped = 0
         self._prefetched = None
         self._teacher_stream = None
+        self._masks = {}
 
     # -- one epoch over the two loaders ----------------------------------------
     def cycle_dataset_sparse_supervised(self, loader_sup, loader_unsup, training=True):
@@ -152,9 +153,18 @@ class LTRSparseTrainer:
                 out[key] = ops.gather_rows(src[key].contiguous(), idx)
         return out, n_keep, idx
 
+    def _mask(self, n, value):
+        key = (n, value)
+        if key not in self._masks:
+            self._masks[key] = torch.full((n,), value, dtype=torch.bool, device=self.device)
+        return self._masks[key]
+
     def _sparse_training(self, data_sup, data_unsup, aug_label, training=True):
         self.actor.train(training)
         with torch.set_grad_enabled(training):
             data_load, n_keep, _ = self.compact(data_unsup, aug_label)
+            # which instances are unsupervised pairs, i.e. take the strong augmentation (:366-368)
+            data_sup["masks"] = self._mask(data_sup["search_anno"].shape[0], False)
+            data_load["masks"] = self._mask(data_load["aug_anno"].shape[0], True)
             loss, stats = self.actor(mode="spsup", burnin_data=data_sup, sp_data=data_load)
         return loss, stats, n_keep

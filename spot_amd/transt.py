@@ -7,8 +7,8 @@ are normalised by the preprocess kernel, ResNet features are projected straight
 from NCHW into batch-first tokens by the GEMM kernel (no permute pass), fusion
 and heads run in libspot_hip.so.
 
-Not implemented (stochastic, outside the parity contract): GrayScale joint
-augmentation and EllipseRotationAffine; brightness jitter is supported.
+The in-network augmentations (brightness jitter, GrayScale, EllipseRotationAffine) are batched device
+kernels (transforms_in_net.py); their random draws come from torch's device generator.
 """
 import torch
 from torch import nn
@@ -17,6 +17,7 @@ from . import ops
 from .backbone import build_backbone
 from .fusion import build_featurefusion_network, _LinearParams
 from .tensordict import NestedTensor, TensorDict
+from .transforms_in_net import EllipseRotationAffine, GrayScale, IndependentTransform, JointTransform
 
 
 class NecessaryPreprocess(nn.Module):
@@ -123,9 +124,6 @@ class TransT(nn.Module):
     def __init__(self, backbone, featurefusion_network, num_classes=1, iou_prediction=False,
                  necessary_pre=None, independent_trans=None, joint_trans=None):
         super().__init__()
-        if independent_trans is not None or joint_trans is not None:
-            raise RuntimeError("spot_amd: in-network GrayScale / EllipseRotationAffine augmentation is not "
-                               "implemented; pass independent_trans=None, joint_trans=None")
         self.featurefusion_network = featurefusion_network
         hidden_dim = featurefusion_network.d_model
         self.class_embed = MLP(hidden_dim, hidden_dim, num_classes + 1, 3)
@@ -199,10 +197,34 @@ class TransT(nn.Module):
                 data[p + "_images"], data[p + "_avg"] = self.necessary_pre(data, tag=p)
         return data
 
-    def forward(self, burnin_data=None, teacher_data=None, sp_data=None):
-        burnin_data = self._preprocess(burnin_data, ["template", "search"])
-        teacher_data = self._preprocess(teacher_data, ["key", "unlabeled"])
+    def _joint(self, data, tags):
+        """Joint transform of a (template, search) pair of groups, e.g. GrayScale (transt_model.py:128-133,157-165)."""
+        image_groups, anno_groups, avg_groups = self.joint_trans(data, tags=tags, masks=data["masks"])
+        for i, tag in enumerate(tags):
+            data[tag + "_images"], data[tag + "_anno"], data[tag + "_avg"] = image_groups[i], anno_groups[i], avg_groups[i]
+
+    def _decode_pairwise_data(self, data, stage, prefixes):
+        """transt_model.py:119-145: necessary transforms, and for burn-in pairs the joint transform."""
+        data = self._preprocess(data, prefixes)
+        if data is not None and stage == "burnin" and self.joint_trans is not None:
+            self._joint(data, prefixes)
+        return data
+
+    def _decode_sp_data(self, sp_data):
+        """transt_model.py:147-185: necessary transforms, joint transform, then the strong augmentation of the
+        search ("aug") crops, whose boxes follow."""
         sp_data = self._preprocess(sp_data, ["relay", "aug"])
+        if sp_data is not None:
+            if self.joint_trans is not None:
+                self._joint(sp_data, ["relay", "aug"])
+            if self.independent_trans is not None:
+                sp_data["aug_images"], sp_data["aug_anno"] = self.independent_trans(sp_data, tag="aug")
+        return sp_data
+
+    def forward(self, burnin_data=None, teacher_data=None, sp_data=None):
+        burnin_data = self._decode_pairwise_data(burnin_data, "burnin", ["template", "search"])
+        teacher_data = self._decode_pairwise_data(teacher_data, "sparse", ["key", "unlabeled"])
+        sp_data = self._decode_sp_data(sp_data)
         templates, searches = [], []
         if teacher_data is not None:
             searches.append(teacher_data["unlabeled_images"])
@@ -244,8 +266,18 @@ def transt_resnet50(settings, network="student"):
         "Network construction type should be in 'student', 'teacher' or 'baseline'."
     backbone_net = build_backbone(settings, backbone_pretrained=False)
     featurefusion_network = build_featurefusion_network(settings)
-    jitter = settings.aug_settings["jitter"] if hasattr(settings, "aug_settings") else 0.0
-    necessary_pre = NecessaryPreprocess(b_j=jitter, mean=settings.normalize_mean, std=settings.normalize_std)
+    aug = getattr(settings, "aug_settings", {})
+    necessary_pre = NecessaryPreprocess(b_j=aug.get("jitter", 0.0), mean=settings.normalize_mean,
+                                        std=settings.normalize_std)
+    # transt_model.py:333-345: the teacher takes neither transform; the strong augmentation needs its settings tag.
+    # (A grey-scale probability of 0 never fires; the transform is then left out instead of drawing for nothing.)
+    joint_trans = independent_trans = None
+    if network != "teacher" and aug.get("gray", 0.0) > 0:
+        joint_trans = JointTransform([GrayScale(gray_probability=aug["gray"])])
+    if network != "teacher" and getattr(settings, "strong_augmentation_tag", False):
+        independent_trans = IndependentTransform([EllipseRotationAffine(
+            max_angle=aug["angle"], lr_flip_prob=aug["lr_f_prob"], ud_flip_prob=aug["ud_f_prob"])])
     model = TransT(backbone_net, featurefusion_network, num_classes=settings.num_classes,
-                   iou_prediction=settings.iou_prediction_tag, necessary_pre=necessary_pre)
+                   iou_prediction=settings.iou_prediction_tag, necessary_pre=necessary_pre,
+                   independent_trans=independent_trans, joint_trans=joint_trans)
     return model.to(torch.device(settings.device))

@@ -592,6 +592,34 @@ def case_preprocess_posenc():
     save("g14_pre_pos", seed=91, img_out=t2n(o), avg_out=t2n(a), mask8=t2n(m), **out)
 
 
+def case_transforms(seed=97):
+    """G16: GrayScale and EllipseRotationAffine of the reference on seeded crops, with the draws they made."""
+    from ltr.models.pre_input import EllipseRotationAffine, GrayScale
+    B, C, H, W = 8, 3, 32, 48
+    img = torch.from_numpy(det_input("img", (B, C, H, W), seed, -2, 2))
+    tmpl = torch.from_numpy(det_input("tmpl", (B, C, 16, 24), seed + 1, -2, 2))
+    avg = torch.from_numpy(det_input("avg", (B, 3), seed, -1, 1))
+    avg_t = torch.from_numpy(det_input("avg_t", (B, 3), seed + 1, -1, 1))
+    bbox = torch.tensor([[10., 8., 12., 9.], [2., 3., 30., 20.], [20., 10., 6., 14.], [0., 0., 47., 31.],
+                         [15., 12., 10., 10.], [30., 5., 12., 20.], [5., 20., 20., 8.], [22., 14., 4., 4.]])
+    mask = torch.tensor([True, True, False, True, True, True, False, True])
+    era = EllipseRotationAffine(max_angle=10, lr_flip_prob=0.35, ud_flip_prob=0.5)
+    torch.manual_seed(seed)
+    im_o, bb_o, _, _ = era(img.clone(), bbox.clone(), avg.clone(), mask)
+    torch.manual_seed(seed)                              # the draws, repeated in the module's order (:161-166)
+    base = 180 * torch.where(torch.rand([B]) <= 0.5, torch.ones([B]), torch.zeros([B]))
+    angle = torch.randint(-10, 11, [B]) + base
+    lr = torch.rand([B]) <= 0.35
+    gs = GrayScale(gray_probability=0.4)
+    torch.manual_seed(seed + 5)
+    groups, _, avgs, _ = gs([tmpl.clone(), img.clone()], [bbox, bbox], [avg_t.clone(), avg.clone()], mask)
+    torch.manual_seed(seed + 5)
+    gray_tag = torch.rand([B]) <= 0.4
+    save("g16_transforms", seed=seed, bbox=t2n(bbox), mask=t2n(mask), angle=t2n(angle), lr_flip=t2n(lr),
+         era_img=t2n(im_o), era_bbox=t2n(bb_o), gray_tag=t2n(gray_tag), gray_tmpl=t2n(groups[0]),
+         gray_img=t2n(groups[1]), gray_avg_t=t2n(avgs[0]), gray_avg=t2n(avgs[1]))
+
+
 def case_student(seed=3):
     """G15: student forward + losses + selected gradients (train mode, dropout 0, no aug).
 
@@ -654,7 +682,7 @@ CASES = {
     "decode": case_decode, "compaction": case_compaction, "boxes": case_boxes,
     "matcher_criterion": case_matcher_criterion, "tracker_post": case_tracker_post,
     "xcorr": case_xcorr, "ema": case_ema, "pre_pos": case_preprocess_posenc,
-    "student": case_student,
+    "student": case_student, "transforms": case_transforms,
 }
 
 

@@ -724,3 +724,40 @@ def test_maxpool3x3s2_vs_torch(ops, B, C, H, W):
     with torch.no_grad():
         assert torch.equal(ops.max_pool_3x3_s2(xt.to(DEV), pool).cpu(), yr.detach())
 
+
+def test_in_network_transforms_golden(golden):
+    """Batched GrayScale / EllipseRotationAffine kernels against the reference's per-sample loop (golden draws)."""
+    from spot_amd.transforms_in_net import EllipseRotationAffine, GrayScale
+    g = golden("g16_transforms")
+    seed = int(g["seed"])
+    B, C, H, W = 8, 3, 32, 48
+    img, tmpl = det_input("img", (B, C, H, W), seed, -2, 2), det_input("tmpl", (B, C, 16, 24), seed + 1, -2, 2)
+    avg, avg_t = det_input("avg", (B, 3), seed, -1, 1), det_input("avg_t", (B, 3), seed + 1, -1, 1)
+    era = EllipseRotationAffine(max_angle=10, lr_flip_prob=0.35, ud_flip_prob=0.25)
+    im, bb = era.apply(G(img), G(g["bbox"]), G(avg), G(g["mask"]), G(g["angle"]), G(g["lr_flip"]))
+    # nearest sampling: a source coordinate within rounding of a pixel boundary may pick the neighbour
+    differ = (im.cpu() != T(g["era_img"])).float().mean().item()
+    assert differ <= 2e-4, differ
+    np.testing.assert_allclose(bb.cpu().numpy(), g["era_bbox"], rtol=0, atol=2e-3)
+    unmasked = ~T(g["mask"])
+    assert torch.equal(im.cpu()[unmasked], T(img)[unmasked])
+    gs = GrayScale(0.4)
+    t_dev, i_dev = G(tmpl), G(img)
+    groups, avgs = gs.apply([t_dev, i_dev], [G(avg_t), G(avg)], G(g["gray_tag"]))
+    assert torch.equal(groups[0].cpu(), T(g["gray_tmpl"])) and torch.equal(groups[1].cpu(), T(g["gray_img"]))
+    np.testing.assert_allclose(avgs[0].cpu().numpy(), g["gray_avg_t"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(avgs[1].cpu().numpy(), g["gray_avg"], rtol=0, atol=1e-6)
+    # full-size crops, all angles of the training configuration incl. the 180-degree turn: against the oracle
+    from oracle import spot_oracle as O
+    Bf = 6
+    big = det_input("big", (Bf, 3, 256, 256), 5, -2, 2)
+    ang = torch.tensor([-10., 7., 180., 173., 0., 190.])
+    lr = torch.tensor([False, True, True, False, True, False])
+    msk = torch.tensor([True, True, True, True, False, True])
+    box = torch.tensor([[100., 90., 60., 40.]] * Bf)
+    favg = T(det_input("favg", (Bf, 3), 6, -1, 1))
+    im2, bb2 = era.apply(G(big), box.to(DEV), favg.to(DEV), msk.to(DEV), ang.to(DEV), lr.to(DEV))
+    ro, rb = O.ellipse_rotation_affine(T(big), box.clone(), favg, msk, ang, lr)
+    assert (im2.cpu() != ro).float().mean().item() <= 2e-4
+    np.testing.assert_allclose(bb2.cpu().numpy(), rb.numpy(), rtol=0, atol=2e-3)
+

@@ -352,3 +352,37 @@ def test_tracker_runs_on_synthetic_sequence():
         o = trk.track(f)
         assert len(o["target_bbox"]) == 4 and np.all(np.isfinite(o["target_bbox"]))
         assert o["best_score"].shape == (1024,)
+
+
+def test_student_forward_with_in_network_augmentation():
+    """The reference's training configuration (grey-scale, rotation, flips): the student forward applies the
+    transforms to the pseudo-labelled pairs only, hands the transformed boxes on as targets, and trains."""
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.criterion import transt_loss
+    from spot_amd.detinit import det_fill_
+    from spot_amd.synthetic import Settings
+    from spot_amd.tensordict import TensorDict
+    from spot_amd.transt import transt_resnet50
+    from tests.test_oracle_model import student_batches
+    S = Settings(device="cpu", dropout=0.0, strong_augmentation_tag=True)
+    S.aug_settings.update(gray=0.5, angle=10, lr_f_prob=0.5, ud_f_prob=0.5)
+    assert transt_resnet50(S, network="teacher").independent_trans is None
+    net = det_fill_(transt_resnet50(S), 23).cuda().train()
+    assert net.independent_trans is not None and net.joint_trans is not None
+    sup, sp = student_batches(23, 2, 6)
+    sup = TensorDict({k: v.cuda() for k, v in sup.items()})
+    sp = TensorDict({k: v.cuda() for k, v in sp.items()})
+    sup["masks"] = torch.zeros(2, dtype=torch.bool, device="cuda")
+    sp["masks"] = torch.ones(6, dtype=torch.bool, device="cuda")
+    anno_in, sup_anno_in = sp["aug_anno"].clone(), sup["search_anno"].clone()
+    torch.manual_seed(5)
+    Sg = Settings(dropout=0.0)
+    actor = TranstSparseActor(Sg, net, net, transt_loss(Sg))
+    loss, stats = actor(mode="spsup", burnin_data=TensorDict(sup), sp_data=TensorDict(sp))
+    assert torch.isfinite(loss)
+    loss.backward()
+    out = net(burnin_data=TensorDict(sup), sp_data=TensorDict(sp))
+    assert torch.equal(out["search_anno"], sup_anno_in)                   # labelled pairs: boxes untouched
+    assert not torch.equal(out["aug_anno"], anno_in)                      # pseudo-labelled pairs: boxes follow
+    assert (out["aug_anno"] >= 0).all()
+

@@ -233,3 +233,26 @@ def test_preprocess_and_posenc(golden):
         np.testing.assert_allclose(p.numpy(), g["pos%d" % hw], rtol=1e-5, atol=1e-6)
     p = O.position_embedding_sine(T(g["mask8"]))
     np.testing.assert_allclose(p.numpy(), g["pos8_masked"], rtol=1e-5, atol=1e-6)
+
+
+def _transform_inputs(g):
+    seed = int(g["seed"])
+    B, C, H, W = 8, 3, 32, 48
+    return (T(det_input("img", (B, C, H, W), seed, -2, 2)), T(det_input("tmpl", (B, C, 16, 24), seed + 1, -2, 2)),
+            T(det_input("avg", (B, 3), seed, -1, 1)), T(det_input("avg_t", (B, 3), seed + 1, -1, 1)))
+
+
+def test_g16_in_network_transforms(golden):
+    """GrayScale and EllipseRotationAffine restated for given draws == the reference run with those draws."""
+    g = golden("g16_transforms")
+    img, tmpl, avg, avg_t = _transform_inputs(g)
+    im, bb = O.ellipse_rotation_affine(img, T(g["bbox"]).clone(), avg, T(g["mask"]), T(g["angle"]), T(g["lr_flip"]))
+    assert torch.equal(im, T(g["era_img"]))
+    np.testing.assert_allclose(bb.numpy(), g["era_bbox"], rtol=0, atol=1e-5)
+    assert bool(T(g["lr_flip"]).any()) and bool((T(g["angle"]).abs() > 90).any())        # flips are exercised
+    imgs, avgs = O.gray_scale([tmpl, img], [avg_t, avg], T(g["gray_tag"]))
+    assert torch.equal(imgs[0], T(g["gray_tmpl"])) and torch.equal(imgs[1], T(g["gray_img"]))
+    np.testing.assert_allclose(avgs[0].numpy(), g["gray_avg_t"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(avgs[1].numpy(), g["gray_avg"], rtol=0, atol=1e-7)
+    assert bool(T(g["gray_tag"]).any()) and not bool(T(g["gray_tag"]).all())
+
