@@ -201,6 +201,16 @@ long spot_conv3x3_winograd_wgrad_ws_floats(int B, int Cin, int Cout, int H, int 
 int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout,
                                     int H, int W, int dilation, int accumulate, hipStream_t stream);
 
+/* Patch matrix of a convolution (the 7x7 / stride 2 stem and layer2's 3x3 / stride 2 of the ResNet,
+ * ltr/models/backbone/resnet.py:61,79,195-196, which then run as GEMMs: spot_amd/ops.py:ConvIm2colFn):
+ * cols[B][Kpad][Ho*Wo], row (ci*kh + ky)*kw + kx holds x[b][ci][oy*stride - pad + ky*dilation][ox*stride - pad +
+ * kx*dilation] (zero outside the map), rows from C*kh*kw up to Kpad are zero.  Ho*Wo must be a multiple of 4.
+ * spot_col2im_f32 is its transpose as a gather: dx[B][C][H][W] = sum of the dcols entries that read that pixel. */
+int spot_im2col_f32(const float* x, float* cols, int B, int C, int H, int W, int kh, int kw, int stride, int pad,
+                    int dilation, int Kpad, hipStream_t stream);
+int spot_col2im_f32(const float* dcols, float* dx, int B, int C, int H, int W, int kh, int kw, int stride, int pad,
+                    int dilation, int Kpad, hipStream_t stream);
+
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet stem (ltr/models/backbone/resnet.py:113,199) on
  * `planes` = B*C maps of H x W (H even, W a multiple of 8).  winner [planes, H/2, W/2] (or null in inference)
  * records which of the nine window positions held the maximum (the first one in row-major order on ties, as

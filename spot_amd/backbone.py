@@ -5,8 +5,8 @@ ltr/models/backbone/transt_backbone.py:55-106 with identical state-dict keys
 (`backbone.0.body.conv1.weight`, `...layer3.5.bn3.running_var`, ...).
 
 The 1x1 convolutions are batched GEMMs of libspot_hip.so on the NCHW maps (ops.conv1x1), the
-stride-1 3x3 convolutions its Winograd F(4x4,3x3) path (ops.conv3x3); the 7x7 stem, the one
-stride-2 3x3 convolution and the max-pool stay with PyTorch-ROCm.  BatchNorm is
+stride-1 3x3 convolutions its Winograd F(4x4,3x3) path (ops.conv3x3), the 7x7 stem and the one
+stride-2 3x3 convolution a patch matrix + GEMM (ops.conv_general), the max-pool its own kernel.  BatchNorm is
 fused with the ReLU / residual add that follow it (batchnorm.hip); everything
 downstream (projection, fusion, heads, decode, filter) is libspot_hip.so.
 The nn.BatchNorm2d modules remain as parameter/buffer holders so state-dict
@@ -89,7 +89,7 @@ class ResNet50Layer3(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = ops.max_pool_3x3_s2(ops.batch_norm_act(self.conv1(x), self.bn1, relu=True), self.maxpool)
+        x = ops.max_pool_3x3_s2(ops.batch_norm_act(ops.conv_general(x, self.conv1), self.bn1, relu=True), self.maxpool)
         return self.layer3(self.layer2(self.layer1(x)))
 
 

@@ -63,6 +63,8 @@ SIGNATURES = {
     "spot_adamw_f32": [vp, vp, vp, vp, vp, i32, vp, vp],
     "spot_gemm_f32": [C.POINTER(GemmDesc), vp],
     "spot_colsum_f32": [vp, i64, vp, i64, i32, vp],
+    "spot_im2col_f32": [vp, vp] + [i32] * 10 + [vp],
+    "spot_col2im_f32": [vp, vp] + [i32] * 10 + [vp],
     "spot_rotate_flip_nearest_f32": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "spot_ellipse_rotate_boxes_f32": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "spot_channel_scale_f32": [vp, vp, i64, i32, vp],

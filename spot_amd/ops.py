@@ -699,6 +699,85 @@ def conv1x1_bn_act(x, conv, bn, relu=False, residual=None):
     return y
 
 
+class ConvIm2colFn(torch.autograd.Function):
+    """Bias-free convolution as patch matrix + GEMM, for the two ResNet convolutions outside the Winograd path: the
+    7x7 / stride 2 stem and layer2's 3x3 / stride 2 (resnet.py:61,79,195-196).  Forward, input gradient (GEMM into
+    patch space, then a gather) and weight gradient (one split-K GEMM over all clips, added into the flat gradient
+    buffer) all run on the library's GEMM; the patch matrix of the forward pass is kept for the weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad, dil):
+        x = _chk(x.contiguous())
+        B, Ci, H, W = x.shape
+        Co, _, kh, kw = weight.shape
+        K = Ci * kh * kw
+        Kpad = (K + 31) // 32 * 32
+        Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        N = Ho * Wo
+        dev = x.device
+        cols = torch.empty((B, Kpad, N), dtype=torch.float32, device=dev)
+        lib.call("spot_im2col_f32", _p(x), _p(cols), B, Ci, H, W, kh, kw, stride, pad, dil, Kpad, _st())
+        if Kpad == K:
+            wp = weight.view(Co, K)
+        else:
+            wp = torch.zeros((Co, Kpad), dtype=torch.float32, device=dev)
+            wp[:, :K] = weight.view(Co, K)
+        y = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=dev)
+        gemm(wp, cols, y, Co, N, Kpad, transB=True, lda=Kpad, ldb=N, ldc=N, batch=B, strideB=Kpad * N, strideC=Co * N)
+        ctx.geo = (B, Ci, H, W, Co, kh, kw, stride, pad, dil, K, Kpad, N)
+        ctx.save_for_backward(cols if ctx.needs_input_grad[1] else None, wp, weight)
+        ctx.params = (weight,)
+        if ctx.needs_input_grad[1]:
+            _sink_expect(weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, wp, weight = ctx.saved_tensors
+        (pw,) = ctx.params
+        B, Ci, H, W, Co, kh, kw, stride, pad, dil, K, Kpad, N = ctx.geo
+        dy = dy.contiguous()
+        dev = dy.device
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dcols = torch.empty((B, Kpad, N), dtype=torch.float32, device=dev)
+            gemm(wp, dy, dcols, Kpad, N, Co, transA=True, transB=True, lda=Kpad, ldb=N, ldc=N, batch=B,
+                 strideB=Co * N, strideC=Kpad * N)
+            dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=dev)
+            lib.call("spot_col2im_f32", _p(dcols), _p(dx), B, Ci, H, W, kh, kw, stride, pad, dil, Kpad, _st())
+        if ctx.needs_input_grad[1]:
+            sk = _sink(pw)
+            direct = sk is not None and Kpad == K
+            dwp = sk.view(Co, K) if direct else torch.zeros((Co, Kpad), dtype=torch.float32, device=dev)
+            gemm(dy, cols, dwp, Co, Kpad, B * N, lda=N, ldb=N, ldc=Kpad, kseg=N, segA=Co * N, segB=Kpad * N,
+                 splitk=_splitk_for(Co, Kpad, B * N), accumulate=True)
+            if sk is not None:
+                if not direct:
+                    sk.view(Co, K).add_(dwp[:, :K])
+                _sink_done(pw)
+            else:
+                dw = dwp[:, :K].reshape(weight.shape)
+        return dx, dw, None, None, None
+
+
+OWN_CONV_IM2COL = os.environ.get("SPOT_OWN_CONV_IM2COL", "1") == "1"
+
+
+def conv_general(x, conv):
+    """nn.Conv2d `conv` applied to x through patch matrix + GEMM where that applies (bias-free, one group, square
+    stride / padding / dilation, output positions per map a multiple of 32), the module itself otherwise."""
+    s, p, d = conv.stride, conv.padding, conv.dilation
+    if (OWN_CONV_IM2COL and x.is_cuda and conv.bias is None and conv.groups == 1 and s[0] == s[1] and p[0] == p[1]
+            and d[0] == d[1] and isinstance(p[0], int)):
+        kh, kw = conv.kernel_size
+        Ho = (x.shape[2] + 2 * p[0] - d[0] * (kh - 1) - 1) // s[0] + 1
+        Wo = (x.shape[3] + 2 * p[0] - d[0] * (kw - 1) - 1) // s[0] + 1
+        if Ho > 0 and Wo > 0 and (Ho * Wo) % 32 == 0:
+            return ConvIm2colFn.apply(x, conv.weight, s[0], p[0], d[0])
+    return conv(x)
+
+
 class MaxPool3x3s2Fn(torch.autograd.Function):
     """nn.MaxPool2d(3, stride=2, padding=1) (resnet.py:113,199): one byte per output remembers the winning window
     position, the backward gathers through it."""
@@ -793,12 +872,15 @@ class Conv3x3Fn(torch.autograd.Function):
 _WINOGRAD_WGRAD = os.environ.get("SPOT_WINOGRAD_WGRAD", "1") == "1"
 
 
-_WINOGRAD_MIN_TILES = int(os.environ.get("SPOT_WINOGRAD_MIN_TILES", "512"))   # below: too little work per transformed GEMM
+# batches with fewer 4x4 tiles than this go to the convolution library instead (-1: always).  Measured on the
+# tracker's single frame (64 tiles on layer3) the Winograd path is as fast as the library's, so the default is 0.
+_WINOGRAD_MIN_TILES = int(os.environ.get("SPOT_WINOGRAD_MIN_TILES", "0"))
 
 
 def conv3x3(x, conv):
     """nn.Conv2d `conv` applied to x: the Winograd path for bias-free 3x3 / stride 1 convolutions with dilation d = 1
-    or 2 and padding d on maps whose sides are multiples of 4d, the convolution library otherwise."""
+    or 2 and padding d on maps whose sides are multiples of 4d; strided ones go to conv_general; what is left
+    (stride-1 convolutions on batches too small for the transformed GEMMs) to the convolution library."""
     B, _, H, W = x.shape
     d = conv.dilation[0]
     if (_WINOGRAD_MIN_TILES >= 0 and x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
@@ -806,6 +888,8 @@ def conv3x3(x, conv):
             and conv.bias is None and H % (4 * d) == 0 and W % (4 * d) == 0
             and B * (H // 4) * (W // 4) >= _WINOGRAD_MIN_TILES):
         return Conv3x3Fn.apply(x, conv.weight, d)
+    if conv.stride != (1, 1):
+        return conv_general(x, conv)
     return conv(x)
 
 

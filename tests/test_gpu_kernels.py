@@ -761,3 +761,26 @@ def test_in_network_transforms_golden(golden):
     assert (im2.cpu() != ro).float().mean().item() <= 2e-4
     np.testing.assert_allclose(bb2.cpu().numpy(), rb.numpy(), rtol=0, atol=2e-3)
 
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,k,s,p,d", [(3, 3, 64, 32, 32, 7, 2, 3, 1), (2, 32, 48, 16, 16, 3, 2, 1, 1),
+                                                 (2, 8, 16, 16, 32, 3, 1, 1, 1), (1, 3, 64, 64, 64, 7, 2, 3, 1)])
+def test_conv_im2col_vs_direct(ops, B, Ci, Co, H, W, k, s, p, d):
+    """Patch matrix + GEMM convolution (stem 7x7 / stride 2, strided 3x3): forward and both gradients against
+    torch's direct convolution in float64."""
+    import torch.nn.functional as F
+    x = det_input("x", (B, Ci, H, W), 1, -1, 1)
+    w = det_input("w", (Co, Ci, k, k), 2, -0.2, 0.2)
+    conv = torch.nn.Conv2d(Ci, Co, k, stride=s, padding=p, dilation=d, bias=False).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(G(w))
+    xg = G(x).requires_grad_()
+    y = ops.conv_general(xg, conv)
+    assert type(y.grad_fn).__name__.startswith("ConvIm2colFn")
+    dy = det_input("dy", tuple(y.shape), 3, -1, 1)
+    y.backward(G(dy))
+    xr, wr = T(x).double().requires_grad_(), T(w).double().requires_grad_()
+    yr = F.conv2d(xr, wr, None, s, p, d)
+    yr.backward(T(dy).double())
+    for got, ref in ((y.detach(), yr.detach()), (xg.grad, xr.grad), (conv.weight.grad, wr.grad)):
+        np.testing.assert_allclose(got.cpu().double().numpy(), ref.numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
+
