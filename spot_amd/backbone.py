@@ -48,9 +48,13 @@ class Bottleneck(nn.Module):
             cb = ops.conv1x1_bn_act
         else:
             cb = lambda t, conv, bn, relu=False, residual=None: ops.batch_norm_act(conv(t), bn, relu=relu, residual=residual)
-        out = cb(x, self.conv1, self.bn1, relu=True)
+        if self.downsample is None and OWN_CONV1X1 and x.is_cuda:
+            # identity branch handed through conv1: its gradient joins conv1's input gradient in one launch
+            out, residual = cb(x, self.conv1, self.bn1, relu=True, passthrough=True)
+        else:
+            out = cb(x, self.conv1, self.bn1, relu=True)
+            residual = cb(x, self.downsample[0], self.downsample[1]) if self.downsample is not None else x
         out = ops.batch_norm_act(ops.conv3x3(out, self.conv2), self.bn2, relu=True)
-        residual = x if self.downsample is None else cb(x, self.downsample[0], self.downsample[1])
         return cb(out, self.conv3, self.bn3, relu=True, residual=residual)
 
 

@@ -620,10 +620,14 @@ class Conv1x1Fn(torch.autograd.Function):
     Per clip the feature map is already a [C, H*W] row-major matrix, so forward, input gradient and weight
     gradient are batched GEMMs on it as it lies: no NHWC round trip (the convolution library transposes
     activations for its weight-gradient kernels), and the weight gradient is summed over the batch by
-    split-K straight into the flat gradient buffer."""
+    split-K straight into the flat gradient buffer.
+
+    With passthrough=True the input is handed on as a second output (the bottleneck's identity branch,
+    resnet.py:86-90): the gradient that arrives for it is then added to W^T dy in that GEMM's epilogue instead of
+    by a separate pass over the map after both gradients exist."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, passthrough=False):
         x = _chk(x.contiguous())
         B, Ci, H, W = x.shape
         Co, HW = weight.shape[0], H * W
@@ -634,10 +638,12 @@ class Conv1x1Fn(torch.autograd.Function):
         ctx.params = (weight,)
         if ctx.needs_input_grad[1]:
             _sink_expect(weight)
+        if passthrough:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         x, weight = ctx.saved_tensors
         (pw,) = ctx.params
         B, Ci, H, W = x.shape
@@ -647,8 +653,10 @@ class Conv1x1Fn(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            if dpass is not None:
+                dpass = dpass.contiguous()
             gemm(w2, dy, dx, Ci, HW, Co, transA=True, transB=True, lda=Ci, ldb=HW, ldc=HW, batch=B,
-                 strideB=Co * HW, strideC=Ci * HW)
+                 strideB=Co * HW, strideC=Ci * HW, residual=dpass, ldres=HW, strideRes=Ci * HW)
         if ctx.needs_input_grad[1]:
             sk = _sink(pw)
             dw = sk.view(Co, Ci) if sk is not None else torch.zeros_like(w2)
@@ -659,23 +667,32 @@ class Conv1x1Fn(torch.autograd.Function):
                 _sink_done(pw)
             else:
                 dw = dw.view_as(weight)
-        return dx, dw
+        return dx, dw, None
 
 
-def conv1x1(x, conv):
-    """Bias-free 1x1 nn.Conv2d `conv` applied to x through the GEMM kernel (stride by subsampling first)."""
+def conv1x1(x, conv, passthrough=False):
+    """Bias-free 1x1 nn.Conv2d `conv` applied to x through the GEMM kernel (stride by subsampling first).
+    passthrough=True (stride 1 only) returns (y, x'), x' being x for the identity branch of a residual block."""
     assert conv.kernel_size == (1, 1) and conv.bias is None and conv.groups == 1 and conv.padding == (0, 0)
     if conv.stride != (1, 1):
+        assert not passthrough
         x = x[:, :, ::conv.stride[0], ::conv.stride[1]]
     if x.shape[2] * x.shape[3] % 32 != 0:       # the batch-summed weight gradient walks K in whole 32-wide tiles per clip
-        return torch.nn.functional.conv2d(x, conv.weight, None)
-    return Conv1x1Fn.apply(x, conv.weight)
+        y = torch.nn.functional.conv2d(x, conv.weight, None)
+        return (y, x) if passthrough else y
+    return Conv1x1Fn.apply(x, conv.weight, passthrough)
 
 
-def conv1x1_bn_act(x, conv, bn, relu=False, residual=None):
+def conv1x1_bn_act(x, conv, bn, relu=False, residual=None, passthrough=False):
     """[relu](bn(conv(x)) [+ residual]) for a bias-free 1x1 convolution.  With `bn` in inference mode (and no
     gradient wanted) the normalisation is a per-output-channel affine map and rides in the GEMM's epilogue together
-    with the residual add and the ReLU: one launch, the map is written once.  Otherwise conv1x1 -> batch_norm_act."""
+    with the residual add and the ReLU: one launch, the map is written once.  Otherwise conv1x1 -> batch_norm_act.
+    passthrough=True returns (result, x') with x' = x for the block's identity branch (see Conv1x1Fn)."""
+    if passthrough:
+        if torch.is_grad_enabled() and x.requires_grad:
+            y, xres = conv1x1(x, conv, passthrough=True)
+            return batch_norm_act(y, bn, relu=relu, residual=residual), xres
+        return conv1x1_bn_act(x, conv, bn, relu=relu, residual=residual), x
     fold = (not bn.training and bn.track_running_stats and x.is_cuda and not torch.is_grad_enabled()
             and conv.kernel_size == (1, 1) and conv.bias is None and conv.groups == 1 and conv.padding == (0, 0))
     xs = x
