@@ -188,18 +188,20 @@ int spot_gemm_f32(const spot_gemm_desc* desc /* host */, hipStream_t stream);
  *   flip = 0: out[B,Cout,H,W] = conv2d(in[B,Cin,H,W], w[Cout,Cin,3,3])                      (forward)
  *   flip = 1: out[B,Cout,H,W] = conv_transpose2d(in[B,Cin,H,W], w[Cin,Cout,3,3])            (input gradient: in = dy,
  *             w = the forward weight as stored, Cin = its output channels, Cout = its input channels)
- * ws: spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W) floats of scratch.  Results differ from a direct
+ * ws: spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W) floats of scratch.  v_keep (may be NULL): 36*Cin*B*(H/4)*(W/4)
+ * floats that receive the transformed input, for spot_conv3x3_winograd_wgrad_f32 to reuse.  Results differ from a direct
  * convolution by fp32 rounding of the transforms (~1e-6 relative to the largest term). */
 long spot_conv3x3_winograd_ws_floats(int B, int Cin, int Cout, int H, int W);
-int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, int B, int Cin, int Cout, int H,
-                              int W, int dilation, int flip, hipStream_t stream);
+int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, float* v_keep, int B, int Cin,
+                              int Cout, int H, int W, int dilation, int flip, hipStream_t stream);
 
 /* Weight gradient of the same convolution in the transformed domain: dw[Cout,Cin,3,3] (+)= G^T (sum over tiles of
  * (A dY A^T) (B^T d B)) G, the tile sum being 36 batched GEMMs.  x [B,Cin,H,W] is the forward input, dy [B,Cout,H,W]
- * the output gradient; accumulate = 1 adds into dw (a slice of a gradient buffer). */
+ * the output gradient; accumulate = 1 adds into dw (a slice of a gradient buffer).  v_kept: the forward call's v_keep
+ * buffer; with it x may be NULL and the input transform is not repeated. */
 long spot_conv3x3_winograd_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W);
-int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout,
-                                    int H, int W, int dilation, int accumulate, hipStream_t stream);
+int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* v_kept, const float* dy, float* dw, float* ws, int B,
+                                    int Cin, int Cout, int H, int W, int dilation, int accumulate, hipStream_t stream);
 
 /* Patch matrix of a convolution (the 7x7 / stride 2 stem and layer2's 3x3 / stride 2 of the ResNet,
  * ltr/models/backbone/resnet.py:61,79,195-196, which then run as GEMMs: spot_amd/ops.py:ConvIm2colFn):

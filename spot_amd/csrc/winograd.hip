@@ -285,8 +285,8 @@ extern "C" long spot_conv3x3_winograd_ws_floats(int B, int Cin, int Cout, int H,
         else kernel<2><<<grid, 256, 0, stream>>>(__VA_ARGS__);                \
     } while (0)
 
-extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, int B, int Cin, int Cout,
-                                         int H, int W, int dilation, int flip, hipStream_t stream) {
+extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, float* v_keep, int B,
+                                         int Cin, int Cout, int H, int W, int dilation, int flip, hipStream_t stream) {
     SPOT_CHECK_ARG(in && w && out && ws, "conv3x3_winograd: null pointer");
     SPOT_CHECK_ARG(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_winograd: bad shape");
     SPOT_CHECK_ARG(dilation == 1 || dilation == 2, "conv3x3_winograd: dilation=%d (1 or 2)", dilation);
@@ -297,9 +297,10 @@ extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float*
     SPOT_CHECK_ARG(Pl * (long)(Cin > Cout ? Cin : Cout) * XI < (1L << 40) && Pl < (1L << 31), "conv3x3_winograd: problem too large");
     const int P = (int)Pl;
     const Sizes s = sizes(B, Cin, Cout, H, W);
+    SPOT_CHECK_ARG(((uintptr_t)v_keep & 15) == 0, "conv3x3_winograd: v_keep must be 16-byte aligned");
     float* U = ws;
-    float* V = U + s.U;
-    float* Mb = V + s.V;
+    float* V = v_keep ? v_keep : U + s.U;
+    float* Mb = U + s.U + s.V;
     wino_weights_kernel<<<spot_ceil_div((long)Cout * Cin, 256), 256, 0, stream>>>(w, U, Cout, Cin, flip);
     SPOT_CHECK_LAUNCH("conv3x3_winograd(weights)");
     WINO_LAUNCH(wino_input_kernel, dilation, dim3(spot_ceil_div(P, 256), Cin), in, V, Cin, H, W, P);
@@ -322,24 +323,29 @@ extern "C" long spot_conv3x3_winograd_wgrad_ws_floats(int B, int Cin, int Cout, 
     return spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W);
 }
 
-extern "C" int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int B, int Cin,
-                                               int Cout, int H, int W, int dilation, int accumulate,
+extern "C" int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* v_kept, const float* dy, float* dw, float* ws,
+                                               int B, int Cin, int Cout, int H, int W, int dilation, int accumulate,
                                                hipStream_t stream) {
-    SPOT_CHECK_ARG(x && dy && dw && ws, "conv3x3_winograd_wgrad: null pointer");
+    SPOT_CHECK_ARG((x || v_kept) && dy && dw && ws, "conv3x3_winograd_wgrad: null pointer");
     SPOT_CHECK_ARG(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_winograd_wgrad: bad shape");
     SPOT_CHECK_ARG(dilation == 1 || dilation == 2, "conv3x3_winograd_wgrad: dilation=%d (1 or 2)", dilation);
     SPOT_CHECK_ARG(H % (4 * dilation) == 0 && W % (4 * dilation) == 0,
                    "conv3x3_winograd_wgrad: H=%d, W=%d must be multiples of %d", H, W, 4 * dilation);
-    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15) == 0, "conv3x3_winograd_wgrad: buffers must be 16-byte aligned");
+    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)v_kept | (uintptr_t)dy | (uintptr_t)ws) & 15) == 0,
+                   "conv3x3_winograd_wgrad: buffers must be 16-byte aligned");
     const long Pl = (long)B * (H / 4) * (W / 4);
     SPOT_CHECK_ARG(Pl * (long)(Cin > Cout ? Cin : Cout) * XI < (1L << 40) && Pl < (1L << 31), "conv3x3_winograd_wgrad: problem too large");
     const int P = (int)Pl;
     const Sizes s = sizes(B, Cin, Cout, H, W);
     float* dU = ws;
-    float* V = dU + s.U;
-    float* dM = V + s.V;
-    WINO_LAUNCH(wino_input_kernel, dilation, dim3(spot_ceil_div(P, 256), Cin), x, V, Cin, H, W, P);
-    SPOT_CHECK_LAUNCH("conv3x3_winograd_wgrad(input)");
+    float* Vown = dU + s.U;
+    float* dM = Vown + s.V;
+    const float* V = v_kept;
+    if (!V) {
+        WINO_LAUNCH(wino_input_kernel, dilation, dim3(spot_ceil_div(P, 256), Cin), x, Vown, Cin, H, W, P);
+        SPOT_CHECK_LAUNCH("conv3x3_winograd_wgrad(input)");
+        V = Vown;
+    }
     WINO_LAUNCH(wino_outgrad_kernel, dilation, dim3(spot_ceil_div(P, 256), Cout), dy, dM, Cout, H, W, P);
     SPOT_CHECK_LAUNCH("conv3x3_winograd_wgrad(output gradient)");
     // dU[xi][co][ci] = sum_p dM[xi][co][p] V[xi][ci][p]: the tile index is the reduction; split it when the 36 output

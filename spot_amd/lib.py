@@ -70,8 +70,8 @@ SIGNATURES = {
     "spot_channel_scale_f32": [vp, vp, i64, i32, vp],
     "spot_maxpool3x3s2_fwd_f32": [vp, vp, vp, i64, i32, i32, vp],
     "spot_maxpool3x3s2_bwd_f32": [vp, vp, vp, i64, i32, i32, vp],
-    "spot_conv3x3_winograd_f32": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
-    "spot_conv3x3_winograd_wgrad_f32": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "spot_conv3x3_winograd_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "spot_conv3x3_winograd_wgrad_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
     "spot_mha_bwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64,
                          i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],

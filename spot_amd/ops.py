@@ -835,14 +835,16 @@ def max_pool_3x3_s2(x, pool):
 # ---------------------------------------------------------------------------
 # 3x3 convolutions of the ResNet bottleneck
 # ---------------------------------------------------------------------------
-def _winograd(inp, weight, Cout, flip, dilation=1):
+def _winograd(inp, weight, Cout, flip, dilation=1, keep_v=False):
+    """keep_v: also return the transformed input [36, Cin, tiles] (for the weight gradient)."""
     B, Cin, H, W = inp.shape
     out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=inp.device)
     ws = torch.empty((lib.load().spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W),), dtype=torch.float32,
                      device=inp.device)
-    lib.call("spot_conv3x3_winograd_f32", _p(inp), _p(weight), _p(out), _p(ws), B, Cin, Cout, H, W, int(dilation),
-             int(flip), _st())
-    return out
+    v = torch.empty((36, Cin, B * (H // 4) * (W // 4)), dtype=torch.float32, device=inp.device) if keep_v else None
+    lib.call("spot_conv3x3_winograd_f32", _p(inp), _p(weight), _p(out), _p(ws), _p(v), B, Cin, Cout, H, W,
+             int(dilation), int(flip), _st())
+    return (out, v) if keep_v else out
 
 
 class Conv3x3Fn(torch.autograd.Function):
@@ -853,16 +855,20 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, dilation=1):
         x = _chk(x.contiguous())
-        ctx.save_for_backward(x, weight)
+        keep = ctx.needs_input_grad[1] and _WINOGRAD_WGRAD        # the transformed input serves the weight gradient too
+        y = _winograd(x, weight, weight.shape[0], False, dilation, keep_v=keep)
+        y, v = y if keep else (y, None)
+        ctx.save_for_backward(None if keep else x, weight, v)
         ctx.params = (weight,)
         ctx.dilation = dilation
-        if ctx.needs_input_grad[1] and _WINOGRAD_WGRAD:
+        ctx.xshape = tuple(x.shape)
+        if keep:
             _sink_expect(weight)
-        return _winograd(x, weight, weight.shape[0], False, dilation)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, v = ctx.saved_tensors
         (pw,) = ctx.params
         dy = dy.contiguous()
         dil = ctx.dilation
@@ -872,13 +878,13 @@ class Conv3x3Fn(torch.autograd.Function):
             dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (dil, dil), (dil, dil), False, (0, 0), 1,
                                                      (False, True, False))[1]
         elif ctx.needs_input_grad[1]:
-            B, Cin, H, W = x.shape
+            B, Cin, H, W = ctx.xshape
             Cout = weight.shape[0]
             sk = _sink(pw)
             dw = sk if sk is not None else torch.empty_like(weight)
             ws = torch.empty((lib.load().spot_conv3x3_winograd_wgrad_ws_floats(B, Cin, Cout, H, W),), dtype=torch.float32,
-                             device=x.device)
-            lib.call("spot_conv3x3_winograd_wgrad_f32", _p(x), _p(dy), _p(dw), _p(ws), B, Cin, Cout, H, W, dil,
+                             device=dy.device)
+            lib.call("spot_conv3x3_winograd_wgrad_f32", _p(x), _p(v), _p(dy), _p(dw), _p(ws), B, Cin, Cout, H, W, dil,
                      int(sk is not None), _st())
             if sk is not None:
                 dw = None

@@ -38,7 +38,7 @@ for name, ci, co, h, k, s, p, d, cnt in shapes:
         tg = timeit(lambda: ops._winograd(dy, w, ci, True, d), 10)
         dwb = torch.empty_like(w)
         wsb = torch.empty((lib.load().spot_conv3x3_winograd_wgrad_ws_floats(B, ci, co, h, h),), device="cuda")
-        tww = timeit(lambda: lib.call("spot_conv3x3_winograd_wgrad_f32", ops._p(x), ops._p(dy), ops._p(dwb), ops._p(wsb),
+        tww = timeit(lambda: lib.call("spot_conv3x3_winograd_wgrad_f32", ops._p(x), None, ops._p(dy), ops._p(dwb), ops._p(wsb),
                                       B, ci, co, h, h, d, 0, ops._st()), 10)
         totw[0] += tw * cnt
         totw[1] += tg * cnt
