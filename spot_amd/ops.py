@@ -22,9 +22,13 @@ def _st():
 class KernelTimer:
     """Optional per-launch timing with HIP events on the launch stream (used by bench.py's roofline leg)."""
 
-    def __init__(self, shapes=False):
+    def __init__(self, shapes=False, only=None):
         self.records = []          # (key, work, start_event, end_event)
         self.shapes = shapes       # key GEMM launches by problem shape as well
+        self.only = set(only) if only else None     # kernel classes to time (None: all); the rest launch untimed
+
+    def wants(self, cls):
+        return self.only is None or cls in self.only
 
     def run(self, key, work, launch):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -389,8 +393,8 @@ def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None,
     if bn is not None:          # (gamma, beta, running_mean, running_var, eps): inference BatchNorm over the rows
         d.bn_gamma, d.bn_beta, d.bn_mean, d.bn_var = (t.data_ptr() for t in bn[:4])
         d.bn_eps = float(bn[4])
-    if TIMER is not None:
-        key = "gemm_%s%s" % ("t" if transA else "n", "n" if transB else "t")
+    key = "gemm_%s%s" % ("t" if transA else "n", "n" if transB else "t")
+    if TIMER is not None and TIMER.wants(key):
         if TIMER.shapes:
             key += " M%d N%d K%d b%d sk%d" % (M, N, K, batch, splitk)
         TIMER.run(key, 2.0 * M * N * K * batch,
@@ -1058,7 +1062,7 @@ def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, ou
     lse = torch.empty((B, nhead, Lq), dtype=torch.float32, device=dev) if want_lse else None
     launch = lambda: lib.call("spot_mha_fwd_bf16" if bf16 else "spot_mha_fwd_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), out.stride(0), _p(lse),
                               _p(kpm), B, Lq, Lk, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), drop_seed, _st())
-    if TIMER is not None:
+    if TIMER is not None and TIMER.wants("mha_fwd"):
         TIMER.run("mha_fwd Lq%d Lk%d B%d" % (Lq, Lk, B) if TIMER.shapes else "mha_fwd", 4.0 * B * nhead * Lq * Lk * dh, launch)
     else:
         launch()
@@ -1066,7 +1070,7 @@ def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, ou
 
 
 def _timed_mha_bwd(B, Lq, Lk, nhead, dh, launch):
-    if TIMER is not None:
+    if TIMER is not None and TIMER.wants("mha_bwd"):
         TIMER.run("mha_bwd Lq%d Lk%d B%d" % (Lq, Lk, B) if TIMER.shapes else "mha_bwd",
                   10.0 * B * nhead * Lq * Lk * dh, launch)
     else:

@@ -7,6 +7,7 @@ mkdir -p $O
 cd $R
 timeout -k 10 400 python3 bench.py > $O/bench.log 2>&1 || exit 1
 tail -c 600 $O/bench.log
+timeout -k 10 400 python3 bench.py --no-cpu-baseline --time-kernels all > $O/bench_all_kernels.log 2>&1 || exit 1
 if [ "$1" = "quick" ]; then
   rm -f $O/microbench.txt
 else
