@@ -1077,8 +1077,35 @@ def _timed_mha_bwd(B, Lq, Lk, nhead, dh, launch):
         launch()
 
 
+class frozen_weights:
+    """Context for inference with weights that do not change between calls (the online tracker): the position
+    tables pos W^T (+ b), which depend on weights and position encodings only, are computed once and reused.
+    Entries are keyed by the operands' addresses, so the context must not span an update of the weights
+    (optimizer step, EMA, load_state_dict); leaving it keeps the entries, clear() drops them."""
+    _active = 0
+    _tables = {}
+
+    def __enter__(self):
+        frozen_weights._active += 1
+        return self
+
+    def __exit__(self, *exc):
+        frozen_weights._active -= 1
+        return False
+
+    @staticmethod
+    def clear():
+        frozen_weights._tables.clear()
+
+
 def _pos_table(pos2, W, b):
     """pos2[R,C] W[N,C]^T + b -> [R,N]: the additive term of (x + pos) W^T + b that does not depend on x."""
+    if frozen_weights._active and not torch.is_grad_enabled():
+        key = (pos2.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else 0, tuple(pos2.shape), tuple(W.shape))
+        hit = frozen_weights._tables.get(key)
+        if hit is None:
+            hit = frozen_weights._tables[key] = (linear_fwd(pos2, W, b), pos2, W, b)   # operands kept alive: addresses stay theirs
+        return hit[0]
     return linear_fwd(pos2, W, b)
 
 
@@ -1105,14 +1132,14 @@ class MHAFn(torch.autograd.Function):
         dev = xq.device
         if self_attn:
             # (x + pos) Wqk^T + b = x Wqk^T + b + pos Wqk^T: the last term is a [R, 2C] table over the q|k columns
-            table = linear_fwd(pos_q, in_w[:2 * Cn], None)
+            table = _pos_table(pos_q, in_w[:2 * Cn], None)
             qkv = linear_fwd(xq2, in_w, in_b, rowbias=table)
             q, k, v = qkv, qkv[:, Cn:], qkv[:, 2 * Cn:]
             ldq = ldk = ldv = 3 * Cn
             kv = None
         else:
             tq = _pos_table(pos_q, in_w[:Cn], in_b[:Cn])
-            tk = linear_fwd(pos_k, in_w[Cn:2 * Cn], None)            # [Rk, C] table over the k columns of k|v
+            tk = _pos_table(pos_k, in_w[Cn:2 * Cn], None)             # [Rk, C] table over the k columns of k|v
             qkv = linear_fwd(xq2, in_w[:Cn], None, rowbias=tq)
             kv = linear_fwd(xkv2, in_w[Cn:], in_b[Cn:], rowbias=tk)
             q, k, v = qkv, kv, kv[:, Cn:]

@@ -42,6 +42,7 @@ class NetWithBackbone:
         return getattr(self.net, name)
 
     def load_network(self):
+        ops.frozen_weights.clear()          # a (re)loaded network: position tables of earlier weights are stale
         if self.net is None:
             from .transt import transt_resnet50
             from .synthetic import Settings
@@ -57,11 +58,11 @@ class NetWithBackbone:
         self.load_network()
 
     def template(self, z):
-        with torch.no_grad():
+        with torch.no_grad(), ops.frozen_weights():
             self.net.template(z)
 
     def track(self, x):
-        with torch.no_grad():
+        with torch.no_grad(), ops.frozen_weights():
             return self.net.track(x)
 
 
