@@ -188,12 +188,23 @@ int spot_gemm_f32(const spot_gemm_desc* desc /* host */, hipStream_t stream);
  *   flip = 0: out[B,Cout,H,W] = conv2d(in[B,Cin,H,W], w[Cout,Cin,3,3])                      (forward)
  *   flip = 1: out[B,Cout,H,W] = conv_transpose2d(in[B,Cin,H,W], w[Cin,Cout,3,3])            (input gradient: in = dy,
  *             w = the forward weight as stored, Cin = its output channels, Cout = its input channels)
- * ws: spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W) floats of scratch.  v_keep (may be NULL): 36*Cin*B*(H/4)*(W/4)
- * floats that receive the transformed input, for spot_conv3x3_winograd_wgrad_f32 to reuse.  Results differ from a direct
+ * ws: spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W) floats of scratch.  opts: see the struct.  Results differ from a direct
  * convolution by fp32 rounding of the transforms (~1e-6 relative to the largest term). */
+typedef struct spot_winograd_opts {
+    float* v_keep;          /* 36*Cin*B*(H/4)*(W/4) floats or NULL: receives the transformed input, for
+                             * spot_conv3x3_winograd_wgrad_f32 to reuse                                                */
+    float* u_keep;          /* 36*Cout*Cin floats or NULL: home of the transformed weights across calls                */
+    int u_valid;            /* u_keep already holds the transform of these weights (frozen weights): not recomputed    */
+    const float* bn_gamma;  /* [Cout] each, or bn_gamma = NULL: inference-mode BatchNorm of the output channels,       */
+    const float* bn_beta;   /* y = y*a + (beta - mean*a), a = gamma / sqrt(var + bn_eps), then ReLU if relu != 0,      */
+    const float* bn_mean;   /* applied in the output transform (nn.BatchNorm2d in eval() + ReLU behind conv2,          */
+    const float* bn_var;    /* ltr/models/backbone/resnet.py:79-81, as the tracker and an eval() teacher run them)     */
+    float bn_eps;
+    int relu;
+} spot_winograd_opts;
 long spot_conv3x3_winograd_ws_floats(int B, int Cin, int Cout, int H, int W);
-int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, float* v_keep, int B, int Cin,
-                              int Cout, int H, int W, int dilation, int flip, hipStream_t stream);
+int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, const spot_winograd_opts* opts /* host, may be NULL */,
+                              int B, int Cin, int Cout, int H, int W, int dilation, int flip, hipStream_t stream);
 
 /* Weight gradient of the same convolution in the transformed domain: dw[Cout,Cin,3,3] (+)= G^T (sum over tiles of
  * (A dY A^T) (B^T d B)) G, the tile sum being 36 batched GEMMs.  x [B,Cin,H,W] is the forward input, dy [B,Cout,H,W]

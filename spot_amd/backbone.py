@@ -54,7 +54,7 @@ class Bottleneck(nn.Module):
         else:
             out = cb(x, self.conv1, self.bn1, relu=True)
             residual = cb(x, self.downsample[0], self.downsample[1]) if self.downsample is not None else x
-        out = ops.batch_norm_act(ops.conv3x3(out, self.conv2), self.bn2, relu=True)
+        out = ops.conv3x3_bn_act(out, self.conv2, self.bn2, relu=True)
         return cb(out, self.conv3, self.bn3, relu=True, residual=residual)
 
 

@@ -145,11 +145,23 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 }
 
 // y tile = A^T M A
+// inference-mode BatchNorm (+ ReLU) of the convolution's output channel, folded into the output transform
+struct OutAffine {
+    const float* gamma; const float* beta; const float* mean; const float* var;
+    float eps;
+    int relu;
+};
+
 template <int D>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, float* __restrict__ y, int C, int H,
-                                                          int W, int P) {
+                                                          int W, int P, OutAffine bn) {
     const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
     if (p >= P) return;
+    float sc = 1.f, sh = 0.f;
+    if (bn.gamma) {                              // same arithmetic as the stand-alone inference kernel
+        sc = bn.gamma[c] / sqrtf(bn.var[c] + bn.eps);
+        sh = bn.beta[c] - bn.mean[c] * sc;
+    }
     const TileGeo<D> g(y, p, c, C, H, W);
     const size_t plane = (size_t)C * P;
     const float* mp = Mb + (size_t)c * P + p;
@@ -167,6 +179,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     for (int i = 0; i < 4; ++i) {
         float o[4];
         at6(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], tmp[i][4], tmp[i][5], o);
+        if (bn.gamma) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = fmaf(o[j], sc, sh);
+                if (bn.relu) o[j] = fmaxf(o[j], 0.f);
+            }
+        }
         if (D == 1) {
             *reinterpret_cast<float4*>(yp + (size_t)i * g.rs) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
@@ -285,8 +304,16 @@ extern "C" long spot_conv3x3_winograd_ws_floats(int B, int Cin, int Cout, int H,
         else kernel<2><<<grid, 256, 0, stream>>>(__VA_ARGS__);                \
     } while (0)
 
-extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, float* v_keep, int B,
-                                         int Cin, int Cout, int H, int W, int dilation, int flip, hipStream_t stream) {
+extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws,
+                                         const spot_winograd_opts* opts, int B, int Cin, int Cout, int H, int W,
+                                         int dilation, int flip, hipStream_t stream) {
+    float* v_keep = opts ? opts->v_keep : nullptr;
+    float* u_keep = opts ? opts->u_keep : nullptr;
+    OutAffine bn = {nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+    if (opts && opts->bn_gamma) {
+        SPOT_CHECK_ARG(opts->bn_beta && opts->bn_mean && opts->bn_var, "conv3x3_winograd: bn_gamma needs bn_beta, bn_mean, bn_var");
+        bn = {opts->bn_gamma, opts->bn_beta, opts->bn_mean, opts->bn_var, opts->bn_eps, opts->relu};
+    }
     SPOT_CHECK_ARG(in && w && out && ws, "conv3x3_winograd: null pointer");
     SPOT_CHECK_ARG(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_winograd: bad shape");
     SPOT_CHECK_ARG(dilation == 1 || dilation == 2, "conv3x3_winograd: dilation=%d (1 or 2)", dilation);
@@ -297,12 +324,14 @@ extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float*
     SPOT_CHECK_ARG(Pl * (long)(Cin > Cout ? Cin : Cout) * XI < (1L << 40) && Pl < (1L << 31), "conv3x3_winograd: problem too large");
     const int P = (int)Pl;
     const Sizes s = sizes(B, Cin, Cout, H, W);
-    SPOT_CHECK_ARG(((uintptr_t)v_keep & 15) == 0, "conv3x3_winograd: v_keep must be 16-byte aligned");
-    float* U = ws;
-    float* V = v_keep ? v_keep : U + s.U;
-    float* Mb = U + s.U + s.V;
-    wino_weights_kernel<<<spot_ceil_div((long)Cout * Cin, 256), 256, 0, stream>>>(w, U, Cout, Cin, flip);
-    SPOT_CHECK_LAUNCH("conv3x3_winograd(weights)");
+    SPOT_CHECK_ARG((((uintptr_t)v_keep | (uintptr_t)u_keep) & 15) == 0, "conv3x3_winograd: v_keep / u_keep must be 16-byte aligned");
+    float* U = u_keep ? u_keep : ws;
+    float* V = v_keep ? v_keep : ws + s.U;
+    float* Mb = ws + s.U + s.V;
+    if (!(u_keep && opts->u_valid)) {
+        wino_weights_kernel<<<spot_ceil_div((long)Cout * Cin, 256), 256, 0, stream>>>(w, U, Cout, Cin, flip);
+        SPOT_CHECK_LAUNCH("conv3x3_winograd(weights)");
+    }
     WINO_LAUNCH(wino_input_kernel, dilation, dim3(spot_ceil_div(P, 256), Cin), in, V, Cin, H, W, P);
     SPOT_CHECK_LAUNCH("conv3x3_winograd(input)");
     spot_gemm_desc d = {};
@@ -314,7 +343,7 @@ extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float*
     d.splitk = 1; d.alpha = 1.f;
     const int rc = spot_gemm_f32(&d, stream);
     if (rc != SPOT_OK) return rc;
-    WINO_LAUNCH(wino_output_kernel, dilation, dim3(spot_ceil_div(P, 256), Cout), Mb, out, Cout, H, W, P);
+    WINO_LAUNCH(wino_output_kernel, dilation, dim3(spot_ceil_div(P, 256), Cout), Mb, out, Cout, H, W, P, bn);
     SPOT_CHECK_LAUNCH("conv3x3_winograd(output)");
     return SPOT_OK;
 }

@@ -37,6 +37,12 @@ class GemmDesc(C.Structure):
     ]
 
 
+class WinogradOpts(C.Structure):
+    """Mirror of ``spot_winograd_opts``."""
+    _fields_ = [("v_keep", vp), ("u_keep", vp), ("u_valid", i32), ("bn_gamma", vp), ("bn_beta", vp), ("bn_mean", vp),
+                ("bn_var", vp), ("bn_eps", f32), ("relu", i32)]
+
+
 # name -> argument ctypes (all return int unless noted); the trailing hipStream_t is a void*
 SIGNATURES = {
     "spot_preprocess_u8_f32": [vp, vp, C.POINTER(f32), C.POINTER(f32), vp, i32, i32, i32, i32, vp],

@@ -839,15 +839,33 @@ def max_pool_3x3_s2(x, pool):
 # ---------------------------------------------------------------------------
 # 3x3 convolutions of the ResNet bottleneck
 # ---------------------------------------------------------------------------
-def _winograd(inp, weight, Cout, flip, dilation=1, keep_v=False):
-    """keep_v: also return the transformed input [36, Cin, tiles] (for the weight gradient)."""
+def _winograd(inp, weight, Cout, flip, dilation=1, keep_v=False, bn=None, relu=False):
+    """keep_v: also return the transformed input [36, Cin, tiles] (for the weight gradient).
+    bn (an eval()-mode nn.BatchNorm2d) / relu: folded into the output transform (inference only)."""
     B, Cin, H, W = inp.shape
     out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=inp.device)
     ws = torch.empty((lib.load().spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W),), dtype=torch.float32,
                      device=inp.device)
     v = torch.empty((36, Cin, B * (H // 4) * (W // 4)), dtype=torch.float32, device=inp.device) if keep_v else None
-    lib.call("spot_conv3x3_winograd_f32", _p(inp), _p(weight), _p(out), _p(ws), _p(v), B, Cin, Cout, H, W,
-             int(dilation), int(flip), _st())
+    opts = None
+    frozen = frozen_weights._active and not torch.is_grad_enabled()
+    if keep_v or bn is not None or frozen:
+        opts = lib.WinogradOpts()
+        opts.v_keep = v.data_ptr() if v is not None else None
+        if frozen:                                   # transformed weights kept across calls (see frozen_weights)
+            key = ("winograd", weight.data_ptr(), tuple(weight.shape), int(flip))
+            hit = frozen_weights._tables.get(key)
+            opts.u_valid = int(hit is not None)
+            if hit is None:
+                hit = frozen_weights._tables[key] = (torch.empty((36 * Cout * Cin,), dtype=torch.float32,
+                                                                 device=inp.device), weight)
+            opts.u_keep = hit[0].data_ptr()
+        if bn is not None:
+            opts.bn_gamma, opts.bn_beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+            opts.bn_mean, opts.bn_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            opts.bn_eps, opts.relu = float(bn.eps), int(relu)
+    lib.call("spot_conv3x3_winograd_f32", _p(inp), _p(weight), _p(out), _p(ws), C.byref(opts) if opts is not None else None,
+             B, Cin, Cout, H, W, int(dilation), int(flip), _st())
     return (out, v) if keep_v else out
 
 
@@ -908,16 +926,28 @@ def conv3x3(x, conv):
     """nn.Conv2d `conv` applied to x: the Winograd path for bias-free 3x3 / stride 1 convolutions with dilation d = 1
     or 2 and padding d on maps whose sides are multiples of 4d; strided ones go to conv_general; what is left
     (stride-1 convolutions on batches too small for the transformed GEMMs) to the convolution library."""
-    B, _, H, W = x.shape
-    d = conv.dilation[0]
-    if (_WINOGRAD_MIN_TILES >= 0 and x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-            and d in (1, 2) and conv.dilation == (d, d) and conv.padding == (d, d) and conv.groups == 1
-            and conv.bias is None and H % (4 * d) == 0 and W % (4 * d) == 0
-            and B * (H // 4) * (W // 4) >= _WINOGRAD_MIN_TILES):
-        return Conv3x3Fn.apply(x, conv.weight, d)
+    if winograd_applies(x, conv):
+        return Conv3x3Fn.apply(x, conv.weight, conv.dilation[0])
     if conv.stride != (1, 1):
         return conv_general(x, conv)
     return conv(x)
+
+
+def winograd_applies(x, conv):
+    B, _, H, W = x.shape
+    d = conv.dilation[0]
+    return (_WINOGRAD_MIN_TILES >= 0 and x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and d in (1, 2) and conv.dilation == (d, d) and conv.padding == (d, d) and conv.groups == 1
+            and conv.bias is None and H % (4 * d) == 0 and W % (4 * d) == 0
+            and B * (H // 4) * (W // 4) >= _WINOGRAD_MIN_TILES)
+
+
+def conv3x3_bn_act(x, conv, bn, relu=False):
+    """[relu](bn(conv(x))) for the bottleneck's 3x3 convolution.  With `bn` in inference mode and no gradient wanted
+    the normalisation and the ReLU ride in the Winograd output transform; otherwise conv3x3 -> batch_norm_act."""
+    if (not bn.training and bn.track_running_stats and not torch.is_grad_enabled() and winograd_applies(x, conv)):
+        return _winograd(_chk(x.contiguous()), conv.weight, conv.weight.shape[0], False, conv.dilation[0], bn=bn, relu=relu)
+    return batch_norm_act(conv3x3(x, conv), bn, relu=relu)
 
 
 # ---------------------------------------------------------------------------

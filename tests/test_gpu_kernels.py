@@ -784,3 +784,35 @@ def test_conv_im2col_vs_direct(ops, B, Ci, Co, H, W, k, s, p, d):
     for got, ref in ((y.detach(), yr.detach()), (xg.grad, xr.grad), (conv.weight.grad, wr.grad)):
         np.testing.assert_allclose(got.cpu().double().numpy(), ref.numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
 
+
+@pytest.mark.parametrize("dil", [1, 2])
+def test_conv3x3_with_folded_inference_batchnorm_and_kept_weights(ops, dil):
+    """eval()-mode BatchNorm + ReLU in the Winograd output transform == convolution -> inference BatchNorm kernel,
+    and with frozen weights the transformed weights are reused across calls (and dropped by clear())."""
+    B, Ci, Co, H, W = 2, 32, 48, 16, 16
+    x = G(det_input("x", (B, Ci, H, W), 1, -1, 1))
+    conv = torch.nn.Conv2d(Ci, Co, 3, padding=dil, dilation=dil, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(Co).to(DEV).eval()
+    with torch.no_grad():
+        conv.weight.copy_(G(det_input("w", (Co, Ci, 3, 3), 2, -0.2, 0.2)))
+        bn.weight.copy_(G(det_input("g", (Co,), 3, 0.5, 1.5)))
+        bn.bias.copy_(G(det_input("b", (Co,), 4, -0.5, 0.5)))
+        bn.running_mean.copy_(G(det_input("m", (Co,), 5, -0.5, 0.5)))
+        bn.running_var.copy_(G(det_input("v", (Co,), 6, 0.5, 2.0)))
+        two_pass = ops.batch_norm_act(ops.conv3x3(x, conv), bn, relu=True)
+        fused = ops.conv3x3_bn_act(x, conv, bn, relu=True)
+        assert torch.equal(fused, two_pass)
+        ops.frozen_weights.clear()
+        with ops.frozen_weights():
+            first = ops.conv3x3_bn_act(x, conv, bn, relu=True)
+            assert len(ops.frozen_weights._tables) == 1
+            again = ops.conv3x3_bn_act(x, conv, bn, relu=True)          # transformed weights not recomputed
+            conv.weight.mul_(2.0)                                       # a weight update inside the context is NOT seen
+            stale = ops.conv3x3_bn_act(x, conv, bn, relu=True)
+        assert torch.equal(first, two_pass) and torch.equal(again, two_pass) and torch.equal(stale, two_pass)
+        ops.frozen_weights.clear()
+        with ops.frozen_weights():
+            fresh = ops.conv3x3_bn_act(x, conv, bn, relu=True)
+        assert not torch.equal(fresh, two_pass)
+        ops.frozen_weights.clear()
+
