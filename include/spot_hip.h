@@ -215,14 +215,16 @@ int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* v_kept, const f
                                     int Cin, int Cout, int H, int W, int dilation, int accumulate, hipStream_t stream);
 
 /* Patch matrix of a convolution (the 7x7 / stride 2 stem and layer2's 3x3 / stride 2 of the ResNet,
- * ltr/models/backbone/resnet.py:61,79,195-196, which then run as GEMMs: spot_amd/ops.py:ConvIm2colFn):
- * cols[B][Kpad][Ho*Wo], row (ci*kh + ky)*kw + kx holds x[b][ci][oy*stride - pad + ky*dilation][ox*stride - pad +
- * kx*dilation] (zero outside the map), rows from C*kh*kw up to Kpad are zero.  Ho*Wo must be a multiple of 4.
+ * ltr/models/backbone/resnet.py:61,79,195-196, and the 3x3 convolutions of the Siamese head on odd-sized maps,
+ * ltr/models/neck/ocean_fusion.py:56-85,126-158, which then run as GEMMs: spot_amd/ops.py:ConvIm2colFn):
+ * cols[B][Kpad][pitch], row (ci*kh + ky)*kw + kx holds x[b][ci][oy*stride - pad + ky*dilation_h][ox*stride - pad +
+ * kx*dilation_w] at column oy*Wo + ox (zero outside the map); rows from C*kh*kw up to Kpad and columns from Ho*Wo
+ * up to pitch are zero.  pitch >= Ho*Wo and a multiple of 4.
  * spot_col2im_f32 is its transpose as a gather: dx[B][C][H][W] = sum of the dcols entries that read that pixel. */
 int spot_im2col_f32(const float* x, float* cols, int B, int C, int H, int W, int kh, int kw, int stride, int pad,
-                    int dilation, int Kpad, hipStream_t stream);
+                    int dilation_h, int dilation_w, int Kpad, int pitch, hipStream_t stream);
 int spot_col2im_f32(const float* dcols, float* dx, int B, int C, int H, int W, int kh, int kw, int stride, int pad,
-                    int dilation, int Kpad, hipStream_t stream);
+                    int dilation_h, int dilation_w, int Kpad, int pitch, hipStream_t stream);
 
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet stem (ltr/models/backbone/resnet.py:113,199) on
  * `planes` = B*C maps of H x W (H even, W a multiple of 8).  winner [planes, H/2, W/2] (or null in inference)
@@ -322,12 +324,24 @@ int spot_groupdw_bwd_f32(const float* x11, const float* x12, const float* x21, c
                          float* dsoftmax_partial, int planes, int hx, int wx, int hz, int wz,
                          hipStream_t stream);
 
+/* ---- Training labels of the Siamese (Ocean) head for B boxes (x, y, w, h on the search patch), one launch
+ * (ltr/models/loss/ocean_label_gen.py:44-66,124-233).  S = response-map side, cell (r, c) is centred at
+ * ((c - S/2) stride + search_sz/2, (r - S/2) stride + search_sz/2).  Any output may be NULL.
+ *   cls   [B,S,S]   1 within `radius` (L1, in cells) of the cell the box centre falls in, else 0
+ *   reg   [B,S,S,4] float64 distances from the cell centre to the box's left, top, right, bottom edge
+ *   reg_w [B,S,S]   1 where all four are > 0 (the centre lies inside the box)
+ *   iou_w [B,S,S]   the same test against the box grown by `expand` times its size (sizes clamped to >= 1) per side */
+int spot_ocean_labels_f32(const float* anno_xywh, float* cls, double* reg, float* reg_w, float* iou_w, int B, int S,
+                          int stride, int search_sz, float expand, int radius, hipStream_t stream);
+
 /* ---- BatchNorm2d fused with the ReLU / residual add that follow it in the ResNet bottleneck
- * (ltr/models/backbone/resnet.py:72-92,196-198), NCHW fp32, HW a multiple of 4.
+ * (ltr/models/backbone/resnet.py:72-92,196-198; the Siamese head's conv-bn-relu stacks,
+ * ltr/models/neck/ocean_fusion.py:56-85,126-158), NCHW fp32.  Planes are walked in packs of four floats when HW is a
+ * multiple of 4 and every map pointer is 16-byte aligned, element by element otherwise (a pack is then one element).
  * Training forward: batch statistics over (N, HW) per channel; y = [relu]((x - mean) rstd gamma + beta [+ residual]);
  * running_mean / running_var updated with `momentum` (unbiased variance), *num_batches_tracked += 1 (all three may be
- * NULL); save_mean / save_rstd [C] for backward; relu_sign [N*C*HW/4] bytes (bit j = element j of the float4 passed
- * the ReLU; NULL when no gradient is needed).  deferred_stats [2C] (may be NULL): receives the batch mean and the
+ * NULL); save_mean / save_rstd [C] for backward; relu_sign: one byte per pack (bit j = element j of the pack passed
+ * the ReLU; NULL when no gradient is needed; forward and backward must see the same pack width).  deferred_stats [2C] (may be NULL): receives the batch mean and the
  * unbiased batch variance for a later spot_batchnorm_apply_deferred (pass the running buffers as NULL then).
  * ws: spot_batchnorm_ws_floats(N, C) floats. */
 long spot_batchnorm_ws_floats(int N, int C);

@@ -541,3 +541,152 @@ def ellipse_rotation_affine(image, bbox, avg, mask, angle, lr_flip_tag):
     mx, mn = tr.max(dim=2).values, tr.min(dim=2).values
     new = torch.stack([mn[:, 0], mn[:, 1], mx[:, 0] - mn[:, 0], mx[:, 1] - mn[:, 1]], dim=1)
     return out, torch.clamp_min(torch.where(mask[:, None], new, bbox), min=0.0)
+
+
+# --------------------------------------------------------------------------
+# Siamese (SP-Ocean) head around the correlation
+# (ltr/models/neck/ocean_fusion.py:14-114,117-171; ltr/models/tracking/ocean_model.py:79-191;
+#  ltr/models/loss/ocean_label_gen.py:44-233; ltr/models/tracking/ocean_criterion.py:42-258)
+# --------------------------------------------------------------------------
+def _seq_bn(x, sd, p, training):
+    """BatchNorm stored as entry p of an nn.Sequential; in training mode the running buffers in sd are updated."""
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                        training=training, momentum=0.1, eps=1e-5)
+
+
+def _conv_bn_relu(x, sd, p, training, padding=0, dilation=1, first=0):
+    x = F.conv2d(x, sd["%s.%d.weight" % (p, first)], sd.get("%s.%d.bias" % (p, first)), padding=padding, dilation=dilation)
+    return F.relu(_seq_bn(x, sd, "%s.%d" % (p, first + 1), training))
+
+
+def ocean_adjust(x, sd, p, training, crop=False):
+    """ocean_fusion.py:22-32: 1x1 conv + bn; crop=True also returns the central part [4:-4, 4:-4]."""
+    y = _seq_bn(F.conv2d(x, sd[p + ".downsample.0.weight"]), sd, p + ".downsample.1", training)
+    return (y, y[:, :, 4:-4, 4:-4]) if crop else y
+
+
+def ocean_matrix(z, x, sd, p, training):
+    """ocean_fusion.py:161-171: unpadded 3x3 conv-bn-relu, dilation 1, (2, 1), (1, 2), for template and search."""
+    zs = [_conv_bn_relu(z, sd, "%s.%s_k" % (p, n), training, dilation=d)
+          for n, d in (("matrix11", 1), ("matrix12", (2, 1)), ("matrix21", (1, 2)))]
+    xs = [_conv_bn_relu(x, sd, "%s.%s_s" % (p, n), training, dilation=d)
+          for n, d in (("matrix11", 1), ("matrix12", (2, 1)), ("matrix21", (1, 2)))]
+    return zs, xs
+
+
+def _torch_groupdw(zs, xs, w):
+    def xc(x, k):
+        b, c = k.shape[:2]
+        o = F.conv2d(x.reshape(1, b * c, *x.shape[2:]), k.reshape(b * c, 1, *k.shape[2:]), groups=b * c)
+        return o.reshape(b, c, *o.shape[2:])
+    sw = F.softmax(w, 0)
+    return sum(sw[i] * xc(xs[i], zs[i]) for i in range(3))
+
+
+def ocean_box_tower(search, kernel, sd, training, towernum=1, batch_iou=0, p=""):
+    """ocean_fusion.py:87-114.  Returns (ltrb, cls, cls_dw, x_reg, pred_ious or None)."""
+    def tower(x, name):
+        for i in range(towernum):
+            x = _conv_bn_relu(x, sd, p + name, training, padding=1, first=3 * i)
+        return x
+    cls_z, cls_x = ocean_matrix(kernel, search, sd, p + "cls_encode", training)
+    reg_z, reg_x = ocean_matrix(kernel, search, sd, p + "reg_encode", training)
+    cls_dw = _torch_groupdw(cls_z, cls_x, sd[p + "cls_dw.weight"])
+    reg_dw = _torch_groupdw(reg_z, reg_x, sd[p + "reg_dw.weight"])
+    x_reg = tower(reg_dw, "bbox_tower")
+    x = sd[p + "adjust"] * F.conv2d(x_reg, sd[p + "bbox_pred.weight"], sd[p + "bbox_pred.bias"], padding=1) + sd[p + "bias"]
+    x = torch.exp(torch.clamp_max(x, 4.7))
+    c = tower(cls_dw, "cls_tower")
+    cls = 0.1 * F.conv2d(c, sd[p + "cls_pred.weight"], sd[p + "cls_pred.bias"], padding=1)
+    ious = None
+    if batch_iou > 0:
+        t = tower(reg_dw.detach()[:batch_iou], "iou_pred_tower")
+        ious = torch.sigmoid(F.conv2d(t, sd[p + "iou_pred.weight"], sd[p + "iou_pred.bias"], padding=1))
+    return x, cls, cls_dw, x_reg, ious
+
+
+def ocean_grid(score_size, search_size, stride=8):
+    """ocean_model.py:79-96: float64 cell centres, x along columns, y along rows."""
+    idx = np.arange(0, score_size) - np.floor(float(score_size // 2))
+    gx, gy = np.meshgrid(idx, idx)
+    return torch.tensor(gx * stride + search_size // 2), torch.tensor(gy * stride + search_size // 2)
+
+
+def ocean_pred_to_image(bbox_pred, search_size, stride=8):
+    """ocean_model.py:104-121 (its grid is float32 there)."""
+    gx, gy = ocean_grid(bbox_pred.shape[-1], search_size, stride)
+    gx, gy = gx.float(), gy.float()
+    return torch.stack([gx - bbox_pred[:, 0], gy - bbox_pred[:, 1], gx + bbox_pred[:, 2], gy + bbox_pred[:, 3]], 1)
+
+
+def ocean_align_offsets(boxes, feat_hw, search_size, stride=8):
+    """ocean_model.py:123-191 for one clip after the other; boxes [B, H*W, 4] -> [B, H*W, 18] as (y, x) pairs."""
+    fh, fw = feat_hw
+    outs = []
+    for b in boxes:
+        idx = torch.arange(-1, 2, dtype=b.dtype)
+        yy, xx = torch.meshgrid(idx, idx, indexing="ij")
+        xx, yy = xx.reshape(-1), yy.reshape(-1)
+        w = (b[:, 2] - b[:, 0] + 1) / stride / 2 - 1
+        h = (b[:, 3] - b[:, 1] + 1) / stride / 2 - 1
+        x = ((b[:, 0] + b[:, 2]) * 0.5 - search_size * 0.5) / stride + fw // 2
+        y = ((b[:, 1] + b[:, 3]) * 0.5 - search_size * 0.5) / stride + fh // 2
+        gy, gx = torch.meshgrid(torch.arange(0, fh), torch.arange(0, fw), indexing="ij")
+        ox = w[:, None] * xx + (x - gx.reshape(-1).type_as(x))[:, None]
+        oy = h[:, None] * yy + (y - gy.reshape(-1).type_as(y))[:, None]
+        outs.append(torch.stack([oy, ox], -1).reshape(b.shape[0], -1))
+    return torch.stack(outs)
+
+
+def ocean_labels(anno_xywh, S, stride, search_sz, expand=0.2, radius=2):
+    """ocean_label_gen.py:44-66,124-233 -> cls [B,S,S] f32, reg [B,S,S,4] f64, reg_w, iou_w [B,S,S] f32."""
+    gx, gy = ocean_grid(S, search_sz, stride)                       # float64
+    x1, y1 = anno_xywh[:, 0], anno_xywh[:, 1]
+    x2, y2 = x1 + anno_xywh[:, 2], y1 + anno_xywh[:, 3]
+
+    def ltrb(a1, b1, a2, b2):
+        return torch.stack([gx[None] - a1[:, None, None], gy[None] - b1[:, None, None],
+                            a2[:, None, None] - gx[None], b2[:, None, None] - gy[None]], -1)
+    reg = ltrb(x1, y1, x2, y2)
+    reg_w = (reg.min(-1).values > 0).float()
+    w, h = torch.clamp_min(x2 - x1, 1), torch.clamp_min(y2 - y1, 1)
+    iou_w = (ltrb(x1 - expand * w, y1 - expand * h, x2 + expand * w, y2 + expand * h).min(-1).values > 0).float()
+    cx = S // 2 + (((x1 + x2) / 2 - search_sz / 2) / stride).long()
+    cy = S // 2 + (((y1 + y2) / 2 - search_sz / 2) / stride).long()
+    r = torch.arange(S)
+    cls = ((r[None, None, :] - cx[:, None, None]).abs() + (r[None, :, None] - cy[:, None, None]).abs() <= radius).float()
+    return cls, reg, reg_w, iou_w
+
+
+def ocean_ltrb_iou(pred, target):
+    """IoU of two boxes given as distances from a common point (ocean_label_gen.py:78-98, ocean_criterion.py:81-100)."""
+    area_t = (target[..., 0] + target[..., 2]) * (target[..., 1] + target[..., 3])
+    area_p = (pred[..., 0] + pred[..., 2]) * (pred[..., 1] + pred[..., 3])
+    wi = torch.min(pred[..., 0], target[..., 0]) + torch.min(pred[..., 2], target[..., 2])
+    hi = torch.min(pred[..., 3], target[..., 3]) + torch.min(pred[..., 1], target[..., 1])
+    inter = wi * hi
+    return (inter + 1.0) / (area_t + area_p - inter + 1.0)
+
+
+def ocean_align_labels(bbox_pred, reg_label, reg_weight):
+    """ocean_label_gen.py:68-104."""
+    return torch.clamp(torch.abs(reg_weight * ocean_ltrb_iou(bbox_pred.permute(0, 2, 3, 1), reg_label)), 0, 1)
+
+
+def ocean_losses(logits, cls_label, align_logits, align_label, bbox_pred, reg_label, reg_weight, pred_ious, iou_weight):
+    """ocean_criterion.py:42-69,117-148,194-258 by index selection, as the reference does it."""
+    bce = torch.nn.BCEWithLogitsLoss()
+
+    def half(value):
+        sel = cls_label.reshape(-1).eq(value).nonzero().squeeze()
+        if sel.dim() == 0:
+            return 0
+        return bce(logits.reshape(-1)[sel], cls_label.reshape(-1)[sel])
+    loss_ce = half(1) * 0.5 + half(0) * 0.5
+    loss_align = bce(align_logits, align_label.unsqueeze(1))
+    pos = torch.nonzero(reg_weight.reshape(-1) > 0).squeeze(1)
+    ious = ocean_ltrb_iou(bbox_pred.permute(0, 2, 3, 1).reshape(-1, 4)[pos], reg_label.reshape(-1, 4)[pos])
+    loss_bbox, iou = (-torch.log(ious)).mean(), ious.mean()
+    err = (align_label.detach() - pred_ious.squeeze(1)).abs()
+    loss_iou = ((err * (iou_weight - reg_weight)).sum() + (err * reg_weight).sum()) / iou_weight.sum()
+    return {"loss_ce": loss_ce, "loss_align": loss_align, "loss_bbox": loss_bbox, "iou": iou, "loss_iou_pred": loss_iou}

@@ -31,11 +31,39 @@ __device__ __forceinline__ float block_sum(float v, float* red) {   // red: 4 fl
 struct Slice {
     int n0, n1;
 };
-// thread's next float4 of the (sample, position) walk: 256 positions further, wrapping into the next samples
-__device__ __forceinline__ void advance(int& n, int& i, int HW4) {
+// A plane is walked in packs of VW floats: VW = 4 (one 16-byte access) when H*W is a multiple of 4, VW = 1 otherwise
+// (the 25x25 and 29x29 maps of the Siamese head, ltr/models/neck/ocean_fusion.py:56-85,126-158).  The sums are
+// grouped (e0 + e1) + (e2 + e3) within a pack.
+template <int VW>
+struct Pack {
+    float e[VW];
+};
+template <int VW>
+__device__ __forceinline__ Pack<VW> ld(const float* __restrict__ p, size_t off) {
+    Pack<VW> r;
+    if constexpr (VW == 4) {
+        const float4 v = reinterpret_cast<const float4*>(p)[off];
+        r.e[0] = v.x; r.e[1] = v.y; r.e[2] = v.z; r.e[3] = v.w;
+    } else {
+        r.e[0] = p[off];
+    }
+    return r;
+}
+template <int VW>
+__device__ __forceinline__ void st(float* __restrict__ p, size_t off, const Pack<VW>& r) {
+    if constexpr (VW == 4) reinterpret_cast<float4*>(p)[off] = make_float4(r.e[0], r.e[1], r.e[2], r.e[3]);
+    else p[off] = r.e[0];
+}
+template <int VW>
+__device__ __forceinline__ float psum(const Pack<VW>& r) {
+    if constexpr (VW == 4) return (r.e[0] + r.e[1]) + (r.e[2] + r.e[3]);
+    else return r.e[0];
+}
+// thread's next pack of the (sample, position) walk: 256 packs further, wrapping into the next samples
+__device__ __forceinline__ void advance(int& n, int& i, int HWV) {
     i += 256;
-    while (i >= HW4) {
-        i -= HW4;
+    while (i >= HWV) {
+        i -= HWV;
         ++n;
     }
 }
@@ -48,18 +76,23 @@ __device__ __forceinline__ Slice slice_of(int N, int S, int s) {
 }
 
 // ---- pass 1 (training): shifted sum and sum of squares per (channel, slice)
+template <int VW>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial, int N,
-                                                       int C, int HW4, int S) {
+                                                       int C, int HWV, int S) {
     __shared__ float red[4];
     const int c = blockIdx.x, s = blockIdx.y;
     const Slice sl = slice_of(N, S, s);
-    const float K = x[(size_t)c * HW4 * 4];
+    const float K = x[(size_t)c * HWV * VW];
     float s1 = 0.f, s2 = 0.f;
-    for (int n = sl.n0 + (int)threadIdx.x / HW4, i = (int)threadIdx.x % HW4; n < sl.n1; advance(n, i, HW4)) {
-        const float4 v = reinterpret_cast<const float4*>(x)[((size_t)n * C + c) * HW4 + i];
-        const float a = v.x - K, b = v.y - K, d = v.z - K, e = v.w - K;
-        s1 += (a + b) + (d + e);
-        s2 += (a * a + b * b) + (d * d + e * e);
+    for (int n = sl.n0 + (int)threadIdx.x / HWV, i = (int)threadIdx.x % HWV; n < sl.n1; advance(n, i, HWV)) {
+        Pack<VW> v = ld<VW>(x, ((size_t)n * C + c) * HWV + i), q;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            v.e[j] -= K;
+            q.e[j] = v.e[j] * v.e[j];
+        }
+        s1 += psum<VW>(v);
+        s2 += psum<VW>(q);
     }
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
@@ -80,8 +113,8 @@ __device__ __forceinline__ void combine(const float* __restrict__ partial, int c
     b = block_sum(pb, red);
 }
 
-// ---- pass 2 (training): normalise, affine, (+ residual), (relu), sign byte
-template <bool RELU, bool RES>
+// ---- pass 2 (training): normalise, affine, (+ residual), (relu), sign byte (bit j: element j of the pack was > 0)
+template <bool RELU, bool RES, int VW>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                        const float* __restrict__ partial,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -89,13 +122,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        long long* __restrict__ tracked, float* __restrict__ y,
                                                        float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                        unsigned char* __restrict__ sign, float* __restrict__ deferred,
-                                                       int N, int C, int HW4, int S, float eps, float momentum) {
+                                                       int N, int C, int HWV, int S, float eps, float momentum) {
     __shared__ float red[4];
     const int c = blockIdx.x, s = blockIdx.y;
     float s1, s2;
     combine(partial, c, S, s1, s2, red);
-    const float M = (float)N * (float)(HW4 * 4);
-    const float K = x[(size_t)c * HW4 * 4];
+    const float M = (float)N * (float)(HWV * VW);
+    const float K = x[(size_t)c * HWV * VW];
     const float dm = s1 / M;
     const float mean = K + dm;
     const float var = fmaxf(s2 / M - dm * dm, 0.f);
@@ -115,66 +148,87 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
     const float a = rstd * gamma[c], b = beta[c] - mean * a;
     const Slice sl = slice_of(N, S, s);
-    for (int n = sl.n0 + (int)threadIdx.x / HW4, i = (int)threadIdx.x % HW4; n < sl.n1; advance(n, i, HW4)) {
-        const size_t off = ((size_t)n * C + c) * HW4 + i;
-        const float4 v = reinterpret_cast<const float4*>(x)[off];
-        float4 o = make_float4(fmaf(v.x, a, b), fmaf(v.y, a, b), fmaf(v.z, a, b), fmaf(v.w, a, b));
+    for (int n = sl.n0 + (int)threadIdx.x / HWV, i = (int)threadIdx.x % HWV; n < sl.n1; advance(n, i, HWV)) {
+        const size_t off = ((size_t)n * C + c) * HWV + i;
+        Pack<VW> o = ld<VW>(x, off);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) o.e[j] = fmaf(o.e[j], a, b);
         if (RES) {
-            const float4 r = reinterpret_cast<const float4*>(res)[off];
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            const Pack<VW> r = ld<VW>(res, off);
+#pragma unroll
+            for (int j = 0; j < VW; ++j) o.e[j] += r.e[j];
         }
         if (RELU) {
-            if (sign) sign[off] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
-            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            unsigned m = 0;
+#pragma unroll
+            for (int j = 0; j < VW; ++j) {
+                m |= (unsigned)(o.e[j] > 0.f) << j;
+                o.e[j] = fmaxf(o.e[j], 0.f);
+            }
+            if (sign) sign[off] = (unsigned char)m;
         }
-        reinterpret_cast<float4*>(y)[off] = o;
+        st<VW>(y, off, o);
     }
 }
 
 // ---- inference: one pass with the running statistics
-template <bool RELU, bool RES>
+template <bool RELU, bool RES, int VW>
 __global__ __launch_bounds__(256) void bn_infer_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ run_mean, const float* __restrict__ run_var,
-                                                       float* __restrict__ y, int N, int C, int HW4, int S, float eps) {
+                                                       float* __restrict__ y, int N, int C, int HWV, int S, float eps) {
     const int c = blockIdx.x, s = blockIdx.y;
     const float a = gamma[c] / sqrtf(run_var[c] + eps), b = beta[c] - run_mean[c] * a;
     const Slice sl = slice_of(N, S, s);
-    for (int n = sl.n0 + (int)threadIdx.x / HW4, i = (int)threadIdx.x % HW4; n < sl.n1; advance(n, i, HW4)) {
-        const size_t off = ((size_t)n * C + c) * HW4 + i;
-        const float4 v = reinterpret_cast<const float4*>(x)[off];
-        float4 o = make_float4(fmaf(v.x, a, b), fmaf(v.y, a, b), fmaf(v.z, a, b), fmaf(v.w, a, b));
+    for (int n = sl.n0 + (int)threadIdx.x / HWV, i = (int)threadIdx.x % HWV; n < sl.n1; advance(n, i, HWV)) {
+        const size_t off = ((size_t)n * C + c) * HWV + i;
+        Pack<VW> o = ld<VW>(x, off);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) o.e[j] = fmaf(o.e[j], a, b);
         if (RES) {
-            const float4 r = reinterpret_cast<const float4*>(res)[off];
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            const Pack<VW> r = ld<VW>(res, off);
+#pragma unroll
+            for (int j = 0; j < VW; ++j) o.e[j] += r.e[j];
         }
-        if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        reinterpret_cast<float4*>(y)[off] = o;
+        if (RELU) {
+#pragma unroll
+            for (int j = 0; j < VW; ++j) o.e[j] = fmaxf(o.e[j], 0.f);
+        }
+        st<VW>(y, off, o);
     }
 }
 
-__device__ __forceinline__ float4 gate(float4 g, unsigned m) {
-    return make_float4((m & 1) ? g.x : 0.f, (m & 2) ? g.y : 0.f, (m & 4) ? g.z : 0.f, (m & 8) ? g.w : 0.f);
+template <int VW>
+__device__ __forceinline__ Pack<VW> gated(const float* __restrict__ dy, const unsigned char* __restrict__ sign, size_t off) {
+    Pack<VW> g = ld<VW>(dy, off);
+    if (sign) {
+        const unsigned m = sign[off];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) g.e[j] = (m >> j & 1) ? g.e[j] : 0.f;
+    }
+    return g;
 }
 
 // ---- backward pass 1: sum g and sum g * xhat per (channel, slice), g = dy gated by the sign byte
+template <int VW>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const unsigned char* __restrict__ sign,
                                                             const float* __restrict__ save_mean,
                                                             const float* __restrict__ save_rstd, float* __restrict__ partial,
-                                                            int N, int C, int HW4, int S) {
+                                                            int N, int C, int HWV, int S) {
     __shared__ float red[4];
     const int c = blockIdx.x, s = blockIdx.y;
     const float mean = save_mean[c], rstd = save_rstd[c];
     const Slice sl = slice_of(N, S, s);
     float sb = 0.f, sg = 0.f;
-    for (int n = sl.n0 + (int)threadIdx.x / HW4, i = (int)threadIdx.x % HW4; n < sl.n1; advance(n, i, HW4)) {
-        const size_t off = ((size_t)n * C + c) * HW4 + i;
-        float4 g = reinterpret_cast<const float4*>(dy)[off];
-        if (sign) g = gate(g, sign[off]);
-        const float4 v = reinterpret_cast<const float4*>(x)[off];
-        sb += (g.x + g.y) + (g.z + g.w);
-        sg += (g.x * (v.x - mean) + g.y * (v.y - mean)) + (g.z * (v.z - mean) + g.w * (v.w - mean));
+    for (int n = sl.n0 + (int)threadIdx.x / HWV, i = (int)threadIdx.x % HWV; n < sl.n1; advance(n, i, HWV)) {
+        const size_t off = ((size_t)n * C + c) * HWV + i;
+        const Pack<VW> g = gated<VW>(dy, sign, off);
+        Pack<VW> v = ld<VW>(x, off);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) v.e[j] = g.e[j] * (v.e[j] - mean);
+        sb += psum<VW>(g);
+        sg += psum<VW>(v);
     }
     sb = block_sum(sb, red);
     sg = block_sum(sg, red);
@@ -185,6 +239,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // ---- backward pass 2: dx = gamma rstd (g - dbeta/M - xhat dgamma/M); d_residual = g
+template <int VW>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const unsigned char* __restrict__ sign,
                                                            const float* __restrict__ save_mean,
@@ -192,7 +247,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ partial,
                                                            float* __restrict__ dx, float* __restrict__ dres,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
-                                                           int C, int HW4, int S, int accumulate) {
+                                                           int C, int HWV, int S, int accumulate) {
     __shared__ float red[4];
     const int c = blockIdx.x, s = blockIdx.y;
     float db, dg;
@@ -202,17 +257,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
     }
     const float mean = save_mean[c], rstd = save_rstd[c];
-    const float M = (float)N * (float)(HW4 * 4);
+    const float M = (float)N * (float)(HWV * VW);
     const float k = gamma[c] * rstd, kb = db / M, kg = dg * rstd / M;
     const Slice sl = slice_of(N, S, s);
-    for (int n = sl.n0 + (int)threadIdx.x / HW4, i = (int)threadIdx.x % HW4; n < sl.n1; advance(n, i, HW4)) {
-        const size_t off = ((size_t)n * C + c) * HW4 + i;
-        float4 g = reinterpret_cast<const float4*>(dy)[off];
-        if (sign) g = gate(g, sign[off]);
-        const float4 v = reinterpret_cast<const float4*>(x)[off];
-        if (dres) reinterpret_cast<float4*>(dres)[off] = g;
-        reinterpret_cast<float4*>(dx)[off] = make_float4(k * (g.x - kb - (v.x - mean) * kg), k * (g.y - kb - (v.y - mean) * kg),
-                                                         k * (g.z - kb - (v.z - mean) * kg), k * (g.w - kb - (v.w - mean) * kg));
+    for (int n = sl.n0 + (int)threadIdx.x / HWV, i = (int)threadIdx.x % HWV; n < sl.n1; advance(n, i, HWV)) {
+        const size_t off = ((size_t)n * C + c) * HWV + i;
+        const Pack<VW> g = gated<VW>(dy, sign, off);
+        Pack<VW> v = ld<VW>(x, off);
+        if (dres) st<VW>(dres, off, g);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) v.e[j] = k * (g.e[j] - kb - (v.e[j] - mean) * kg);
+        st<VW>(dx, off, v);
     }
 }
 
@@ -224,7 +279,9 @@ int split_for(int N, int C) {
     return S;
 }
 
-bool shape_ok(int N, int C, int HW) { return N > 0 && C > 0 && HW > 0 && HW % 4 == 0 && C <= 65535; }
+bool shape_ok(int N, int C, int HW) { return N > 0 && C > 0 && HW > 0 && C <= 65535; }
+// 16-byte packs need whole float4s per plane and aligned buffers; anything else is walked element by element
+bool vec4(int HW, uintptr_t ptrs) { return HW % 4 == 0 && (ptrs & 15) == 0; }
 
 }  // namespace
 
@@ -235,24 +292,32 @@ extern "C" int spot_batchnorm_fwd_train_f32(const float* x, const float* residua
                                             float* y, float* save_mean, float* save_rstd, unsigned char* relu_sign,
                                             float* deferred_stats, float* ws, int N, int C, int HW, float eps,
                                             float momentum, int relu, hipStream_t stream) {
-    SPOT_CHECK_ARG(shape_ok(N, C, HW), "batchnorm_fwd_train: bad shape N=%d C=%d HW=%d (HW must be a multiple of 4)", N, C, HW);
+    SPOT_CHECK_ARG(shape_ok(N, C, HW), "batchnorm_fwd_train: bad shape N=%d C=%d HW=%d", N, C, HW);
     SPOT_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd && ws, "batchnorm_fwd_train: null pointer");
     SPOT_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "batchnorm_fwd_train: running stats come in pairs");
-    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0, "batchnorm_fwd_train: 16-byte alignment");
+    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 3) == 0, "batchnorm_fwd_train: 4-byte alignment");
+    const bool v4 = vec4(HW, (uintptr_t)x | (uintptr_t)y | (uintptr_t)residual);
     SPOT_CHECK_ARG(relu || !relu_sign, "batchnorm_fwd_train: a sign buffer only makes sense with relu");
     const int S = split_for(N, C);
     dim3 grid(C, S);
-    bn_stats_kernel<<<grid, 256, 0, stream>>>(x, ws, N, C, HW / 4, S);
+    if (v4) bn_stats_kernel<4><<<grid, 256, 0, stream>>>(x, ws, N, C, HW / 4, S);
+    else bn_stats_kernel<1><<<grid, 256, 0, stream>>>(x, ws, N, C, HW, S);
     SPOT_CHECK_LAUNCH("batchnorm_fwd_train(stats)");
-#define SPOT_BN_APPLY(R, A)                                                                                             \
-    bn_apply_kernel<R, A><<<grid, 256, 0, stream>>>(x, residual, ws, gamma, beta, running_mean, running_var,             \
-                                                    num_batches_tracked, y, save_mean, save_rstd, relu_sign,            \
-                                                    deferred_stats, N, C, HW / 4, S, eps, momentum)
+#define SPOT_BN_APPLY_V(R, A, V)                                                                                        \
+    bn_apply_kernel<R, A, V><<<grid, 256, 0, stream>>>(x, residual, ws, gamma, beta, running_mean, running_var,          \
+                                                       num_batches_tracked, y, save_mean, save_rstd, relu_sign,         \
+                                                       deferred_stats, N, C, HW / V, S, eps, momentum)
+#define SPOT_BN_APPLY(R, A)                \
+    do {                                   \
+        if (v4) SPOT_BN_APPLY_V(R, A, 4);  \
+        else SPOT_BN_APPLY_V(R, A, 1);     \
+    } while (0)
     if (relu && residual) SPOT_BN_APPLY(true, true);
     else if (relu) SPOT_BN_APPLY(true, false);
     else if (residual) SPOT_BN_APPLY(false, true);
     else SPOT_BN_APPLY(false, false);
 #undef SPOT_BN_APPLY
+#undef SPOT_BN_APPLY_V
     SPOT_CHECK_LAUNCH("batchnorm_fwd_train(apply)");
     return SPOT_OK;
 }
@@ -260,18 +325,25 @@ extern "C" int spot_batchnorm_fwd_train_f32(const float* x, const float* residua
 extern "C" int spot_batchnorm_fwd_infer_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                                             const float* running_mean, const float* running_var, float* y, int N, int C,
                                             int HW, float eps, int relu, hipStream_t stream) {
-    SPOT_CHECK_ARG(shape_ok(N, C, HW), "batchnorm_fwd_infer: bad shape N=%d C=%d HW=%d (HW must be a multiple of 4)", N, C, HW);
+    SPOT_CHECK_ARG(shape_ok(N, C, HW), "batchnorm_fwd_infer: bad shape N=%d C=%d HW=%d", N, C, HW);
     SPOT_CHECK_ARG(x && gamma && beta && running_mean && running_var && y, "batchnorm_fwd_infer: null pointer");
-    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0, "batchnorm_fwd_infer: 16-byte alignment");
+    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 3) == 0, "batchnorm_fwd_infer: 4-byte alignment");
+    const bool v4 = vec4(HW, (uintptr_t)x | (uintptr_t)y | (uintptr_t)residual);
     const int S = split_for(N, C);
     dim3 grid(C, S);
-#define SPOT_BN_INFER(R, A) \
-    bn_infer_kernel<R, A><<<grid, 256, 0, stream>>>(x, residual, gamma, beta, running_mean, running_var, y, N, C, HW / 4, S, eps)
+#define SPOT_BN_INFER_V(R, A, V) \
+    bn_infer_kernel<R, A, V><<<grid, 256, 0, stream>>>(x, residual, gamma, beta, running_mean, running_var, y, N, C, HW / V, S, eps)
+#define SPOT_BN_INFER(R, A)                \
+    do {                                   \
+        if (v4) SPOT_BN_INFER_V(R, A, 4);  \
+        else SPOT_BN_INFER_V(R, A, 1);     \
+    } while (0)
     if (relu && residual) SPOT_BN_INFER(true, true);
     else if (relu) SPOT_BN_INFER(true, false);
     else if (residual) SPOT_BN_INFER(false, true);
     else SPOT_BN_INFER(false, false);
 #undef SPOT_BN_INFER
+#undef SPOT_BN_INFER_V
     SPOT_CHECK_LAUNCH("batchnorm_fwd_infer");
     return SPOT_OK;
 }
@@ -280,16 +352,22 @@ extern "C" int spot_batchnorm_bwd_f32(const float* dy, const float* x, const uns
                                       const float* save_mean, const float* save_rstd, const float* gamma, float* dx,
                                       float* d_residual, float* dgamma, float* dbeta, float* ws, int N, int C, int HW,
                                       int accumulate, hipStream_t stream) {
-    SPOT_CHECK_ARG(shape_ok(N, C, HW), "batchnorm_bwd: bad shape N=%d C=%d HW=%d (HW must be a multiple of 4)", N, C, HW);
+    SPOT_CHECK_ARG(shape_ok(N, C, HW), "batchnorm_bwd: bad shape N=%d C=%d HW=%d", N, C, HW);
     SPOT_CHECK_ARG(dy && x && save_mean && save_rstd && gamma && dx && ws, "batchnorm_bwd: null pointer");
-    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)d_residual) & 15) == 0,
-                   "batchnorm_bwd: 16-byte alignment");
+    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)d_residual) & 3) == 0,
+                   "batchnorm_bwd: 4-byte alignment");
+    const bool v4 = vec4(HW, (uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)d_residual);
     const int S = split_for(N, C);
     dim3 grid(C, S);
-    bn_bwd_reduce_kernel<<<grid, 256, 0, stream>>>(dy, x, relu_sign, save_mean, save_rstd, ws, N, C, HW / 4, S);
+    if (v4) bn_bwd_reduce_kernel<4><<<grid, 256, 0, stream>>>(dy, x, relu_sign, save_mean, save_rstd, ws, N, C, HW / 4, S);
+    else bn_bwd_reduce_kernel<1><<<grid, 256, 0, stream>>>(dy, x, relu_sign, save_mean, save_rstd, ws, N, C, HW, S);
     SPOT_CHECK_LAUNCH("batchnorm_bwd(reduce)");
-    bn_bwd_apply_kernel<<<grid, 256, 0, stream>>>(dy, x, relu_sign, save_mean, save_rstd, gamma, ws, dx, d_residual, dgamma,
-                                                  dbeta, N, C, HW / 4, S, accumulate);
+    if (v4)
+        bn_bwd_apply_kernel<4><<<grid, 256, 0, stream>>>(dy, x, relu_sign, save_mean, save_rstd, gamma, ws, dx, d_residual,
+                                                         dgamma, dbeta, N, C, HW / 4, S, accumulate);
+    else
+        bn_bwd_apply_kernel<1><<<grid, 256, 0, stream>>>(dy, x, relu_sign, save_mean, save_rstd, gamma, ws, dx, d_residual,
+                                                         dgamma, dbeta, N, C, HW, S, accumulate);
     SPOT_CHECK_LAUNCH("batchnorm_bwd(apply)");
     return SPOT_OK;
 }

@@ -66,6 +66,17 @@ def det_fill_(module, seed=0):
     return module
 
 
+def det_fill_positive_norm_(module, seed=0):
+    """det_fill_, then every BatchNorm scale mapped to 0.5 + 5 |w|: for modules whose normalisation layers sit in
+    nn.Sequential containers (names like ``tower.1.weight``), which the name rules above do not recognise."""
+    det_fill_(module, seed)
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.weight is not None:
+                m.weight.copy_(0.5 + 5.0 * m.weight.abs())
+    return module
+
+
 def det_input(name, shape, seed=0, lo=0.0, hi=1.0, dtype=np.float32):
     """Deterministic synthetic input tensor (numpy)."""
     rng = _rng("input:" + name, seed)

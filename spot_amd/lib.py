@@ -69,11 +69,12 @@ SIGNATURES = {
     "spot_adamw_f32": [vp, vp, vp, vp, vp, i32, vp, vp],
     "spot_gemm_f32": [C.POINTER(GemmDesc), vp],
     "spot_colsum_f32": [vp, i64, vp, i64, i32, vp],
-    "spot_im2col_f32": [vp, vp] + [i32] * 10 + [vp],
-    "spot_col2im_f32": [vp, vp] + [i32] * 10 + [vp],
+    "spot_im2col_f32": [vp, vp] + [i32] * 12 + [vp],
+    "spot_col2im_f32": [vp, vp] + [i32] * 12 + [vp],
     "spot_rotate_flip_nearest_f32": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "spot_ellipse_rotate_boxes_f32": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "spot_channel_scale_f32": [vp, vp, i64, i32, vp],
+    "spot_ocean_labels_f32": [vp] * 5 + [i32] * 4 + [f32, i32, vp],
     "spot_maxpool3x3s2_fwd_f32": [vp, vp, vp, i64, i32, i32, vp],
     "spot_maxpool3x3s2_bwd_f32": [vp, vp, vp, i64, i32, i32, vp],
     "spot_conv3x3_winograd_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],

@@ -721,81 +721,96 @@ def conv1x1_bn_act(x, conv, bn, relu=False, residual=None, passthrough=False):
 
 
 class ConvIm2colFn(torch.autograd.Function):
-    """Bias-free convolution as patch matrix + GEMM, for the two ResNet convolutions outside the Winograd path: the
-    7x7 / stride 2 stem and layer2's 3x3 / stride 2 (resnet.py:61,79,195-196).  Forward, input gradient (GEMM into
-    patch space, then a gather) and weight gradient (one split-K GEMM over all clips, added into the flat gradient
-    buffer) all run on the library's GEMM; the patch matrix of the forward pass is kept for the weight gradient."""
+    """Convolution as patch matrix + GEMM, for what lies outside the Winograd path: the ResNet's 7x7 / stride 2 stem
+    and layer2's 3x3 / stride 2 (resnet.py:61,79,195-196), and the Siamese head's 3x3 convolutions on odd-sized maps,
+    some with a bias, some dilated along one axis (ocean_fusion.py:56-85,126-158).  Forward, input gradient (GEMM
+    into patch space, then a gather) and weight gradient (one split-K GEMM over all clips, added into the flat
+    gradient buffer) all run on the library's GEMM; the patch matrix of the forward pass is kept for the weight
+    gradient.  Maps whose position count is not a multiple of 32 are worked on at a row pitch rounded up to one
+    (zero-filled), so every GEMM keeps whole, aligned tiles; the result is narrowed on the way out."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, dil):
+    def forward(ctx, x, weight, stride, pad, dil, bias=None):
         x = _chk(x.contiguous())
+        dh, dw_ = (dil, dil) if isinstance(dil, int) else dil
         B, Ci, H, W = x.shape
         Co, _, kh, kw = weight.shape
         K = Ci * kh * kw
         Kpad = (K + 31) // 32 * 32
-        Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
-        Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        Ho = (H + 2 * pad - dh * (kh - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dw_ * (kw - 1) - 1) // stride + 1
         N = Ho * Wo
+        Np = (N + 31) // 32 * 32
         dev = x.device
-        cols = torch.empty((B, Kpad, N), dtype=torch.float32, device=dev)
-        lib.call("spot_im2col_f32", _p(x), _p(cols), B, Ci, H, W, kh, kw, stride, pad, dil, Kpad, _st())
+        cols = torch.empty((B, Kpad, Np), dtype=torch.float32, device=dev)
+        lib.call("spot_im2col_f32", _p(x), _p(cols), B, Ci, H, W, kh, kw, stride, pad, dh, dw_, Kpad, Np, _st())
         if Kpad == K:
             wp = weight.view(Co, K)
         else:
             wp = torch.zeros((Co, Kpad), dtype=torch.float32, device=dev)
             wp[:, :K] = weight.view(Co, K)
-        y = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=dev)
-        gemm(wp, cols, y, Co, N, Kpad, transB=True, lda=Kpad, ldb=N, ldc=N, batch=B, strideB=Kpad * N, strideC=Co * N)
-        ctx.geo = (B, Ci, H, W, Co, kh, kw, stride, pad, dil, K, Kpad, N)
+        y = torch.empty((B, Co, Np), dtype=torch.float32, device=dev)
+        gemm(wp, cols, y, Co, Np, Kpad, transB=True, lda=Kpad, ldb=Np, ldc=Np, batch=B, strideB=Kpad * Np, strideC=Co * Np)
+        if Np != N:
+            y = y[:, :, :N] + bias.view(1, Co, 1) if bias is not None else y[:, :, :N].contiguous()
+        elif bias is not None:
+            y += bias.view(1, Co, 1)
+        ctx.geo = (B, Ci, H, W, Co, kh, kw, stride, pad, dh, dw_, K, Kpad, N, Np)
         ctx.save_for_backward(cols if ctx.needs_input_grad[1] else None, wp, weight)
         ctx.params = (weight,)
         if ctx.needs_input_grad[1]:
             _sink_expect(weight)
-        return y
+        return y.view(B, Co, Ho, Wo)
 
     @staticmethod
     def backward(ctx, dy):
         cols, wp, weight = ctx.saved_tensors
         (pw,) = ctx.params
-        B, Ci, H, W, Co, kh, kw, stride, pad, dil, K, Kpad, N = ctx.geo
-        dy = dy.contiguous()
+        B, Ci, H, W, Co, kh, kw, stride, pad, dh, dw_, K, Kpad, N, Np = ctx.geo
         dev = dy.device
+        dbias = dy.sum((0, 2, 3)) if ctx.needs_input_grad[5] else None
+        if Np != N:
+            dyp = torch.zeros((B, Co, Np), dtype=torch.float32, device=dev)
+            dyp[:, :, :N] = dy.reshape(B, Co, N)
+            dy = dyp
+        else:
+            dy = dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dcols = torch.empty((B, Kpad, N), dtype=torch.float32, device=dev)
-            gemm(wp, dy, dcols, Kpad, N, Co, transA=True, transB=True, lda=Kpad, ldb=N, ldc=N, batch=B,
-                 strideB=Co * N, strideC=Kpad * N)
+            dcols = torch.empty((B, Kpad, Np), dtype=torch.float32, device=dev)
+            gemm(wp, dy, dcols, Kpad, Np, Co, transA=True, transB=True, lda=Kpad, ldb=Np, ldc=Np, batch=B,
+                 strideB=Co * Np, strideC=Kpad * Np)
             dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=dev)
-            lib.call("spot_col2im_f32", _p(dcols), _p(dx), B, Ci, H, W, kh, kw, stride, pad, dil, Kpad, _st())
+            lib.call("spot_col2im_f32", _p(dcols), _p(dx), B, Ci, H, W, kh, kw, stride, pad, dh, dw_, Kpad, Np, _st())
         if ctx.needs_input_grad[1]:
             sk = _sink(pw)
             direct = sk is not None and Kpad == K
             dwp = sk.view(Co, K) if direct else torch.zeros((Co, Kpad), dtype=torch.float32, device=dev)
-            gemm(dy, cols, dwp, Co, Kpad, B * N, lda=N, ldb=N, ldc=Kpad, kseg=N, segA=Co * N, segB=Kpad * N,
-                 splitk=_splitk_for(Co, Kpad, B * N), accumulate=True)
+            gemm(dy, cols, dwp, Co, Kpad, B * Np, lda=Np, ldb=Np, ldc=Kpad, kseg=Np, segA=Co * Np, segB=Kpad * Np,
+                 splitk=_splitk_for(Co, Kpad, B * Np), accumulate=True)
             if sk is not None:
                 if not direct:
                     sk.view(Co, K).add_(dwp[:, :K])
                 _sink_done(pw)
             else:
                 dw = dwp[:, :K].reshape(weight.shape)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, dbias
 
 
 OWN_CONV_IM2COL = os.environ.get("SPOT_OWN_CONV_IM2COL", "1") == "1"
 
 
 def conv_general(x, conv):
-    """nn.Conv2d `conv` applied to x through patch matrix + GEMM where that applies (bias-free, one group, square
-    stride / padding / dilation, output positions per map a multiple of 32), the module itself otherwise."""
+    """nn.Conv2d `conv` applied to x through patch matrix + GEMM where that applies (one group, square stride and
+    padding, zero padding mode), the module itself otherwise."""
     s, p, d = conv.stride, conv.padding, conv.dilation
-    if (OWN_CONV_IM2COL and x.is_cuda and conv.bias is None and conv.groups == 1 and s[0] == s[1] and p[0] == p[1]
-            and d[0] == d[1] and isinstance(p[0], int)):
+    if (OWN_CONV_IM2COL and x.is_cuda and conv.groups == 1 and s[0] == s[1] and isinstance(p, tuple) and p[0] == p[1]
+            and conv.padding_mode == "zeros" and x.dtype == torch.float32):
         kh, kw = conv.kernel_size
         Ho = (x.shape[2] + 2 * p[0] - d[0] * (kh - 1) - 1) // s[0] + 1
-        Wo = (x.shape[3] + 2 * p[0] - d[0] * (kw - 1) - 1) // s[0] + 1
-        if Ho > 0 and Wo > 0 and (Ho * Wo) % 32 == 0:
-            return ConvIm2colFn.apply(x, conv.weight, s[0], p[0], d[0])
+        Wo = (x.shape[3] + 2 * p[0] - d[1] * (kw - 1) - 1) // s[0] + 1
+        if Ho > 0 and Wo > 0:
+            return ConvIm2colFn.apply(x, conv.weight, s[0], p[0], (d[0], d[1]), conv.bias)
     return conv(x)
 
 
@@ -969,7 +984,9 @@ class BatchNormActFn(torch.autograd.Function):
         mean = torch.empty((Cn,), dtype=torch.float32, device=dev)
         rstd = torch.empty((Cn,), dtype=torch.float32, device=dev)
         need = any(ctx.needs_input_grad)
-        sign = torch.empty((x.numel() // 4,), dtype=torch.uint8, device=dev) if (relu and need) else None
+        # one byte per pack of four elements, or per element on maps whose H*W is not a multiple of 4
+        sign = (torch.empty((x.numel() // 4 if HW % 4 == 0 else x.numel(),), dtype=torch.uint8, device=dev)
+                if (relu and need) else None)
         ws = torch.empty((lib.load().spot_batchnorm_ws_floats(N, Cn),), dtype=torch.float32, device=dev)
         lib.call("spot_batchnorm_fwd_train_f32", _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean),
                  _p(running_var), _p(tracked), _p(y), _p(mean), _p(rstd), _p(sign), _p(deferred), _p(ws), N, Cn, HW,
@@ -1056,8 +1073,6 @@ class defer_running_stats:
 def batch_norm_act(x, bn, relu=False, residual=None):
     """nn.BatchNorm2d `bn` applied to x, then (+ residual) and (ReLU), as one fused op.
     Training mode uses batch statistics and updates bn's running buffers like the module would."""
-    if x.shape[2] * x.shape[3] % 4 != 0:
-        raise RuntimeError("spot_amd: fused BatchNorm needs H*W to be a multiple of 4, got %dx%d" % tuple(x.shape[2:]))
     if bn.training or not bn.track_running_stats:
         if bn.momentum is None:
             raise RuntimeError("spot_amd: cumulative-average BatchNorm (momentum=None) is not supported")

@@ -16,9 +16,15 @@ How the reference is imported (all CPU, torch 2.x):
     (`processing_utils.py`, `middleware.py`) are loaded by file path instead.
   * `tensorboard` is absent; `ltr.admin.tensorboard` (a logging writer the
     trainer module imports, never called here) is replaced by an empty class.
-  * The Ocean modules need a compiled CUDA extension and cannot be imported;
-    the depthwise cross-correlation golden is produced by executing the same
-    ATen call the reference makes (grouped `F.conv2d`) on seeded inputs.
+  * `ltr/models/neck/ocean_fusion.py` imports the package of the compiled
+    deformable-convolution extension, which does not exist here.  The
+    depthwise cross-correlation golden (G12) is produced by executing the same
+    ATen call the reference makes (grouped `F.conv2d`) on seeded inputs.  For
+    the head's towers, label generator and criterion (G17) that package is
+    replaced by a module object whose `DeformConv` raises when constructed
+    (nothing in G17 constructs it), and `Tensor.cuda()` is a no-op while the
+    case runs (the reference moves its grids and one parameter to the GPU at
+    construction); everything in G17 is then the reference's own code on CPU.
   * Weights: seeded, from spot_amd.detinit (no checkpoints exist offline);
     `backbone_pretrained=False` (the pretrained path is a network fetch).
   * Everything runs in eval() with the MHA fast path disabled, jitter 0,
@@ -620,6 +626,103 @@ def case_transforms(seed=97):
          gray_img=t2n(groups[1]), gray_avg_t=t2n(avgs[0]), gray_avg=t2n(avgs[1]))
 
 
+def case_ocean(seed=23):
+    """G17: the Siamese head around the correlation: neck, box_tower (encoders, correlation, towers, heads) forward
+    and gradients in train mode, forward in eval mode, pred_to_image / offsets, label generator, criterion."""
+    import torch.nn as nn
+    from spot_amd.detinit import det_fill_positive_norm_
+
+    class _Absent(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError("deformable convolution needs the compiled extension")
+
+    dcn = types.ModuleType("ltr.models.neck.dcn")
+    dcn.DeformConv = _Absent
+    sys.modules["ltr.models.neck.dcn"] = dcn
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        from ltr.models.neck.ocean_fusion import AdjustLayer, box_tower
+        from ltr.models.loss.ocean_label_gen import OceanLabelGenerator
+        from ltr.models.tracking.ocean_criterion import SetCriterionOcean
+        from ltr.models.tracking.ocean_model import Ocean
+        B, Cb, Ch, S = 3, 32, 16, 25
+        out = {"dims": [B, Cb, Ch, S]}
+        # ---- neck + tower, train mode, with gradients
+        neck = det_fill_positive_norm_(AdjustLayer(Cb, Ch), seed).train()
+        tower = det_fill_positive_norm_(box_tower(inchannels=Ch, outchannels=Ch, towernum=1, iou_prediction=True),
+                                        seed + 1).train()
+        xf = torch.from_numpy(det_input("xf", (B, Cb, 31, 31), seed, -1, 1)).requires_grad_()
+        zf = torch.from_numpy(det_input("zf", (B, Cb, 15, 15), seed, -1, 1)).requires_grad_()
+        _, z = neck(zf, crop=True)
+        x = neck(xf, crop=False)
+        bbox, cls, cls_feat, reg_feat, extra = tower(x, z, iou_prediction=True, batch_iou=2)
+        ups = {k: torch.from_numpy(det_input("up_" + k, tuple(v.shape), seed, -1, 1))
+               for k, v in (("bbox", bbox), ("cls", cls), ("iou", extra["pred_ious"]), ("reg_feat", reg_feat))}
+        ((bbox * ups["bbox"]).sum() + (cls * ups["cls"]).sum() + (extra["pred_ious"] * ups["iou"]).sum()
+         + (reg_feat * ups["reg_feat"]).sum()).backward()
+        out.update(train_bbox=t2n(bbox), train_cls=t2n(cls), train_cls_feat=t2n(cls_feat), train_reg_feat=t2n(reg_feat),
+                   train_ious=t2n(extra["pred_ious"]), d_xf=t2n(xf.grad), d_zf=t2n(zf.grad))
+        for name in ("cls_encode.matrix12_k.0.weight", "reg_encode.matrix21_s.0.weight", "reg_encode.matrix11_s.1.weight",
+                     "bbox_tower.0.weight", "bbox_tower.0.bias", "bbox_tower.1.bias", "bbox_pred.weight", "bbox_pred.bias",
+                     "cls_pred.weight", "iou_pred.weight", "adjust", "bias", "cls_dw.weight", "reg_dw.weight"):
+            out["dtower." + name] = t2n(dict(tower.named_parameters())[name].grad)
+        out["dneck.downsample.0.weight"] = t2n(neck.downsample[0].weight.grad)
+        out["neck_running_mean"] = t2n(neck.downsample[1].running_mean)
+        out["tower_running_var"] = t2n(tower.bbox_tower[1].running_var)
+        # ---- eval mode (tracker path): running statistics
+        neck.eval(), tower.eval()
+        with torch.no_grad():
+            _, z = neck(zf, crop=True)
+            x = neck(xf, crop=False)
+            bbox_e, cls_e, _, reg_e, _ = tower(x, z, iou_prediction=False)
+        out.update(eval_bbox=t2n(bbox_e), eval_cls=t2n(cls_e), eval_reg_feat=t2n(reg_e))
+        # ---- box decoding and align offsets (methods of the model class, called unbound on a bare namespace)
+        ns = types.SimpleNamespace(score_size=S, search_size=255, batch=B, training=True)
+        Ocean.grids(ns)
+        p2i = Ocean.pred_to_image(ns, bbox_e)
+        offs = Ocean.offset(ns, p2i.permute(0, 2, 3, 1).reshape(B, -1, 4), bbox_e.shape)
+        out.update(pred_to_image=t2n(p2i), offsets=t2n(offs))
+        # ---- labels and losses
+        st = types.SimpleNamespace(stride=8, output_sz=S, batch_size=8, search_sz=255, search_feature_sz=S,
+                                   weight_dict={}, device="cpu")
+        gen = OceanLabelGenerator(st)
+        anno = torch.tensor([[90., 100., 60., 50.], [20., 30., 120., 80.], [127., 127., 1., 1.], [200., 10., 80., 60.],
+                             [-20., -10., 100., 90.], [100.5, 99.25, 40.75, 61.5], [60., 70., 0.5, 0.25],
+                             [30., 180., 150., 40.]])
+        cls_l = gen({"anno": anno}, tag="cls")
+        reg_l, reg_w = gen({"anno": anno}, tag="reg")
+        iou_w = gen({"anno": anno}, tag="iou_w")
+        n = anno.shape[0]
+        pred = torch.from_numpy(det_input("pred_ltrb", (n, 4, S, S), seed, 1, 90)).requires_grad_()
+        align_l = gen({"bbox_pred": pred, "reg_label": reg_l, "reg_weight": reg_w}, tag="align")
+        logits = torch.from_numpy(det_input("logits", (n, 1, S, S), seed, -3, 3)).requires_grad_()
+        align_logits = torch.from_numpy(det_input("align_logits", (n, 1, S, S), seed, -3, 3)).requires_grad_()
+        pred_ious = torch.from_numpy(det_input("pred_ious", (n, 1, S, S), seed, 0, 1)).requires_grad_()
+        crit = SetCriterionOcean(st, ["cls", "align_cls", "boxes"])
+        outputs = {"pred_logits_sup": logits, "cls_label_sup": cls_l, "align_label_sup": align_l,
+                   "align_logits_sup": align_logits, "pred_boxes_sup": pred, "reg_label_sup": reg_l,
+                   "reg_weight_sup": reg_w, "pred_ious_sup": pred_ious, "iou_weight_sup": iou_w}
+        losses = crit(outputs, None, tag="sup")
+        total = losses["loss_ce"] + 1.2 * losses["loss_align"] + 1.5 * losses["loss_bbox"] + 0.7 * losses["loss_iou_pred"]
+        total.backward()
+        out.update(anno=t2n(anno), cls_label=t2n(cls_l), reg_label=t2n(reg_l), reg_weight=t2n(reg_w), iou_weight=t2n(iou_w),
+                   align_label=t2n(align_l), d_pred=t2n(pred.grad), d_logits=t2n(logits.grad),
+                   d_align_logits=t2n(align_logits.grad), d_pred_ious=t2n(pred_ious.grad))
+        for k, v in losses.items():
+            out["loss." + k] = t2n(v)
+        # a batch whose classification map has exactly one positive cell... cannot occur (radius 2 gives 13 cells, fewer
+        # only off the map); the single-cell rule is exercised with a hand-made label instead
+        one = torch.zeros(1, S, S)
+        one[0, 3, 4] = 1.0
+        lg = torch.from_numpy(det_input("one_logits", (1, 1, S, S), seed, -3, 3))
+        out["loss_ce_single_positive"] = t2n(crit._weighted_BCE(lg, one))
+    finally:
+        torch.Tensor.cuda = real_cuda
+        del sys.modules["ltr.models.neck.dcn"]
+    save("g17_ocean", seed=seed, **out)
+
+
 def case_student(seed=3):
     """G15: student forward + losses + selected gradients (train mode, dropout 0, no aug).
 
@@ -682,7 +785,7 @@ CASES = {
     "decode": case_decode, "compaction": case_compaction, "boxes": case_boxes,
     "matcher_criterion": case_matcher_criterion, "tracker_post": case_tracker_post,
     "xcorr": case_xcorr, "ema": case_ema, "pre_pos": case_preprocess_posenc,
-    "student": case_student, "transforms": case_transforms,
+    "student": case_student, "transforms": case_transforms, "ocean": case_ocean,
 }
 
 

@@ -131,7 +131,7 @@ def test_two_convolution_paths_agree_at_layer3_size(ops):
     B, Cn, H = 40, 256, 32
     x, w, dy = _r(1, B, Cn, H, H), _r(2, Cn, Cn, 3, 3) * 0.05, _r(3, B, Cn, H, H)
     outs = []
-    for fn in (lambda a, b: ops.Conv3x3Fn.apply(a, b, 1), lambda a, b: ops.ConvIm2colFn.apply(a, b, 1, 1, 1)):
+    for fn in (lambda a, b: ops.Conv3x3Fn.apply(a, b, 1), lambda a, b: ops.ConvIm2colFn.apply(a, b, 1, 1, 1, None)):
         xa, wa = x.clone().requires_grad_(), w.clone().requires_grad_()
         y = fn(xa, wa)
         y.backward(dy)

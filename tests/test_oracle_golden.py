@@ -256,3 +256,89 @@ def test_g16_in_network_transforms(golden):
     np.testing.assert_allclose(avgs[1].numpy(), g["gray_avg"], rtol=0, atol=1e-7)
     assert bool(T(g["gray_tag"]).any()) and not bool(T(g["gray_tag"]).all())
 
+
+
+def _ocean_state(g):
+    """Seeded parameters of the Siamese head's neck and tower, as the golden run filled them."""
+    from spot_amd import ocean
+    from spot_amd.detinit import det_fill_positive_norm_
+    B, Cb, Ch, S = (int(v) for v in g["dims"])
+    seed = int(g["seed"])
+    neck = det_fill_positive_norm_(ocean.AdjustLayer(Cb, Ch), seed)
+    tower = det_fill_positive_norm_(ocean.box_tower(inchannels=Ch, outchannels=Ch, towernum=1, iou_prediction=True), seed + 1)
+    xf, zf = T(det_input("xf", (B, Cb, 31, 31), seed, -1, 1)), T(det_input("zf", (B, Cb, 15, 15), seed, -1, 1))
+    return neck, tower, xf, zf
+
+
+def test_g17_ocean_head_forward_and_gradients(golden):
+    """Neck + box_tower restated == the reference's modules, train mode (with gradients) and eval mode."""
+    g = golden("g17_ocean")
+    neck, tower, xf, zf = _ocean_state(g)
+    seed = int(g["seed"])
+    nsd = {k: v.clone() for k, v in neck.state_dict().items()}
+    tsd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in tower.state_dict().items()}
+    for k in list(tsd):
+        if "running" in k:
+            tsd[k] = tsd[k].detach()
+    nsd["downsample.0.weight"].requires_grad_()
+    xf.requires_grad_(), zf.requires_grad_()
+    _, z = O.ocean_adjust(zf, _prefixed(nsd), "n", True, crop=True)
+    x = O.ocean_adjust(xf, _prefixed(nsd), "n", True)
+    bbox, cls, cls_feat, reg_feat, ious = O.ocean_box_tower(x, z, tsd, True, batch_iou=2)
+    for name, got in (("train_bbox", bbox), ("train_cls", cls), ("train_cls_feat", cls_feat), ("train_reg_feat", reg_feat),
+                      ("train_ious", ious)):
+        np.testing.assert_allclose(got.detach().numpy(), g[name], rtol=1e-4, atol=1e-5, err_msg=name)
+    ups = {k: T(det_input("up_" + k, tuple(v.shape), seed, -1, 1))
+           for k, v in (("bbox", bbox), ("cls", cls), ("iou", ious), ("reg_feat", reg_feat))}
+    ((bbox * ups["bbox"]).sum() + (cls * ups["cls"]).sum() + (ious * ups["iou"]).sum() + (reg_feat * ups["reg_feat"]).sum()).backward()
+    for key in (k for k in g.files if k.startswith("dtower.") and not k.endswith("tower.0.bias")):
+        want = g[key]
+        np.testing.assert_allclose(tsd[key[len("dtower."):]].grad.numpy(), want, rtol=2e-3, atol=2e-4 * np.abs(want).max(),
+                                   err_msg=key)
+    for got, key in ((xf.grad, "d_xf"), (zf.grad, "d_zf"), (nsd["downsample.0.weight"].grad, "dneck.downsample.0.weight")):
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=2e-3, atol=2e-4 * np.abs(g[key]).max(), err_msg=key)
+    # the train-mode passes (template, then search) updated the running statistics
+    np.testing.assert_allclose(nsd["downsample.1.running_mean"].numpy(), g["neck_running_mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tsd["bbox_tower.1.running_var"].numpy(), g["tower_running_var"], rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        _, z = O.ocean_adjust(zf, _prefixed(nsd), "n", False, crop=True)
+        x = O.ocean_adjust(xf, _prefixed(nsd), "n", False)
+        bbox_e, cls_e, _, reg_e, none = O.ocean_box_tower(x, z, tsd, False)
+    assert none is None
+    for name, got in (("eval_bbox", bbox_e), ("eval_cls", cls_e), ("eval_reg_feat", reg_e)):
+        np.testing.assert_allclose(got.numpy(), g[name], rtol=1e-4, atol=1e-5, err_msg=name)
+    np.testing.assert_allclose(O.ocean_pred_to_image(T(g["eval_bbox"]), 255).numpy(), g["pred_to_image"], rtol=0, atol=1e-5)
+    B, S = int(g["dims"][0]), int(g["dims"][3])
+    offs = O.ocean_align_offsets(T(g["pred_to_image"]).permute(0, 2, 3, 1).reshape(B, -1, 4), (S, S), 255)
+    np.testing.assert_allclose(offs.numpy(), g["offsets"], rtol=1e-6, atol=1e-5)
+
+
+def _prefixed(sd, p="n"):
+    """View of a state dict under a name prefix (tensors shared, so in-place running-statistics updates land in sd)."""
+    return {p + "." + k: v for k, v in sd.items()}
+
+
+def test_g17_ocean_labels_and_losses(golden):
+    """Label generator and criterion restated == the reference's, bit for bit on the labels."""
+    g = golden("g17_ocean")
+    S, seed = int(g["dims"][3]), int(g["seed"])
+    anno = T(g["anno"])
+    n = anno.shape[0]
+    cls, reg, reg_w, iou_w = O.ocean_labels(anno, S, 8, 255)
+    assert reg.dtype == torch.float64 and g["reg_label"].dtype == np.float64
+    for got, key in ((cls, "cls_label"), (reg, "reg_label"), (reg_w, "reg_weight"), (iou_w, "iou_weight")):
+        assert np.array_equal(got.numpy(), g[key]), key
+    assert 0 < g["reg_weight"].sum() < g["iou_weight"].sum() and g["cls_label"].sum() > 0
+    pred = T(det_input("pred_ltrb", (n, 4, S, S), seed, 1, 90)).requires_grad_()
+    align = O.ocean_align_labels(pred, reg, reg_w)
+    np.testing.assert_allclose(align.detach().numpy(), g["align_label"], rtol=1e-12, atol=0)
+    logits = T(det_input("logits", (n, 1, S, S), seed, -3, 3)).requires_grad_()
+    align_logits = T(det_input("align_logits", (n, 1, S, S), seed, -3, 3)).requires_grad_()
+    pred_ious = T(det_input("pred_ious", (n, 1, S, S), seed, 0, 1)).requires_grad_()
+    losses = O.ocean_losses(logits, cls, align_logits, align, pred, reg, reg_w, pred_ious, iou_w)
+    for k, v in losses.items():
+        np.testing.assert_allclose(v.detach().numpy(), g["loss." + k], rtol=1e-6, atol=1e-7, err_msg=k)
+    (losses["loss_ce"] + 1.2 * losses["loss_align"] + 1.5 * losses["loss_bbox"] + 0.7 * losses["loss_iou_pred"]).backward()
+    for got, key in ((pred.grad, "d_pred"), (logits.grad, "d_logits"), (align_logits.grad, "d_align_logits"),
+                     (pred_ious.grad, "d_pred_ious")):
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-5, atol=1e-9, err_msg=key)
