@@ -324,6 +324,24 @@ int spot_groupdw_bwd_f32(const float* x11, const float* x12, const float* x21, c
                          float* dsoftmax_partial, int planes, int hx, int wx, int hz, int wz,
                          hipStream_t stream);
 
+/* ---- Deformable convolution v1 (ltr/models/neck/dcn/src/deform_conv_cuda_kernel.cu:189-275 deformable_im2col,
+ * :277-369 deformable_col2im, :371-463 deformable_col2im_coord; called from deform_conv_cuda.cpp:149-482 through
+ * ltr/models/neck/dcn/deform_conv.py:12-110).  x [B,C,H,W]; offset [B, deformable_groups*2*kh*kw, Ho, Wo] holds
+ * (dy, dx) per tap; square stride / padding / dilation.  The sampled patch matrix cols[B][Kpad][pitch] has the layout
+ * of spot_im2col_f32 (row (ci*kh + ky)*kw + kx, column oy*Wo + ox, zero beyond C*kh*kw rows and Ho*Wo columns), so the
+ * products with the weights are spot_gemm_f32 calls (spot_amd/ops.py:DeformConvFn).
+ * spot_deform_col2im_f32: from dcols (= W^T dy, same layout) the input gradient dx [B,C,H,W] (cleared here, then
+ * accumulated with float atomics; may be NULL) and the offset gradient doffset (same shape as offset; may be NULL;
+ * needs ws of spot_deform_col2im_ws_floats(...) floats). */
+int spot_deform_im2col_f32(const float* x, const float* offset, float* cols, int B, int C, int H, int W, int kh, int kw,
+                           int stride, int pad, int dilation, int deformable_groups, int Kpad, int pitch,
+                           hipStream_t stream);
+long spot_deform_col2im_ws_floats(int B, int C, int H, int W, int kh, int kw, int stride, int pad, int dilation,
+                                  int deformable_groups);
+int spot_deform_col2im_f32(const float* dcols, const float* x, const float* offset, float* dx, float* doffset, float* ws,
+                           int B, int C, int H, int W, int kh, int kw, int stride, int pad, int dilation,
+                           int deformable_groups, int Kpad, int pitch, hipStream_t stream);
+
 /* ---- Training labels of the Siamese (Ocean) head for B boxes (x, y, w, h on the search patch), one launch
  * (ltr/models/loss/ocean_label_gen.py:44-66,124-233).  S = response-map side, cell (r, c) is centred at
  * ((c - S/2) stride + search_sz/2, (r - S/2) stride + search_sz/2).  Any output may be NULL.

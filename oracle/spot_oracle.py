@@ -690,3 +690,43 @@ def ocean_losses(logits, cls_label, align_logits, align_label, bbox_pred, reg_la
     err = (align_label.detach() - pred_ious.squeeze(1)).abs()
     loss_iou = ((err * (iou_weight - reg_weight)).sum() + (err * reg_weight).sum()) / iou_weight.sum()
     return {"loss_ce": loss_ce, "loss_align": loss_align, "loss_bbox": loss_bbox, "iou": iou, "loss_iou_pred": loss_iou}
+
+
+# --------------------------------------------------------------------------
+# deformable convolution v1 (ltr/models/neck/dcn/src/deform_conv_cuda_kernel.cu:82-113,189-241; gradients :115-186,
+# 277-333,371-434 are what autograd derives from this forward wherever the sample point is not on a pixel row/column)
+# PARITY UNPINNED: the reference holds no fixture for this operator and its extension cannot be built or run here;
+# this restates the published DCNv1 algorithm as the reference's kernel source implements it.
+# --------------------------------------------------------------------------
+def deform_conv(x, offset, weight, stride=1, pad=0, dil=1, dgroups=1):
+    """x [B,C,H,W], offset [B, dgroups*2*kh*kw, Ho, Wo] as (dy, dx) per tap, weight [Co,C,kh,kw] -> [B,Co,Ho,Wo]."""
+    B, C, H, W = x.shape
+    Co, _, kh, kw = weight.shape
+    Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    oy = (torch.arange(Ho, dtype=x.dtype) * stride - pad).view(1, Ho, 1)
+    ox = (torch.arange(Wo, dtype=x.dtype) * stride - pad).view(1, 1, Wo)
+    cpg = C // dgroups
+    flat = x.reshape(B, C, H * W)
+    groups = []
+    for dg in range(dgroups):
+        xs = flat[:, dg * cpg:(dg + 1) * cpg]
+        taps = []
+        for tap in range(kh * kw):
+            ky, kx = divmod(tap, kw)
+            h = oy + ky * dil + offset[:, dg * 2 * kh * kw + 2 * tap]
+            w = ox + kx * dil + offset[:, dg * 2 * kh * kw + 2 * tap + 1]
+            valid = (h > -1) & (w > -1) & (h < H) & (w < W)
+            hl, wl = torch.floor(h.detach()), torch.floor(w.detach())
+            lh, lw = h - hl, w - wl
+
+            def at(hi, wi):
+                inb = (valid & (hi >= 0) & (hi <= H - 1) & (wi >= 0) & (wi <= W - 1)).view(B, 1, -1)
+                idx = (hi.clamp(0, H - 1) * W + wi.clamp(0, W - 1)).long().view(B, 1, -1).expand(B, cpg, -1)
+                return xs.gather(2, idx) * inb
+            lh_, lw_ = lh.reshape(B, 1, -1), lw.reshape(B, 1, -1)
+            taps.append((1 - lh_) * (1 - lw_) * at(hl, wl) + (1 - lh_) * lw_ * at(hl, wl + 1)
+                        + lh_ * (1 - lw_) * at(hl + 1, wl) + lh_ * lw_ * at(hl + 1, wl + 1))
+        groups.append(torch.stack(taps, 2))                      # [B, cpg, taps, N]
+    cols = torch.cat(groups, 1).reshape(B, C * kh * kw, Ho * Wo)
+    return (weight.reshape(Co, -1) @ cols).reshape(B, Co, Ho, Wo)

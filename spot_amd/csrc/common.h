@@ -30,6 +30,16 @@ void spot_set_error(const char* fmt, ...);
         }                                                                         \
     } while (0)
 
+// Around a HIP runtime call (memset, copy) issued from an entry point.
+#define SPOT_CHECK_HIP(call)                                                          \
+    do {                                                                              \
+        hipError_t e__ = (call);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            spot_set_error("%s failed: %s", #call, hipGetErrorString(e__));           \
+            return SPOT_ERR_LAUNCH;                                                   \
+        }                                                                             \
+    } while (0)
+
 static inline int spot_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 #define WAVE 64

@@ -75,6 +75,8 @@ SIGNATURES = {
     "spot_ellipse_rotate_boxes_f32": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "spot_channel_scale_f32": [vp, vp, i64, i32, vp],
     "spot_ocean_labels_f32": [vp] * 5 + [i32] * 4 + [f32, i32, vp],
+    "spot_deform_im2col_f32": [vp] * 3 + [i32] * 12 + [vp],
+    "spot_deform_col2im_f32": [vp] * 6 + [i32] * 12 + [vp],
     "spot_maxpool3x3s2_fwd_f32": [vp, vp, vp, i64, i32, i32, vp],
     "spot_maxpool3x3s2_bwd_f32": [vp, vp, vp, i64, i32, i32, vp],
     "spot_conv3x3_winograd_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -116,6 +118,8 @@ def load():
     lib.spot_conv3x3_winograd_ws_floats.argtypes = [i32, i32, i32, i32, i32]
     lib.spot_conv3x3_winograd_wgrad_ws_floats.restype = i64
     lib.spot_conv3x3_winograd_wgrad_ws_floats.argtypes = [i32, i32, i32, i32, i32]
+    lib.spot_deform_col2im_ws_floats.restype = i64
+    lib.spot_deform_col2im_ws_floats.argtypes = [i32] * 10
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.restype = i32

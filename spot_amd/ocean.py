@@ -126,6 +126,67 @@ class box_tower(nn.Module):
         return x, cls, cls_dw, x_reg, extra
 
 
+class DeformConv(nn.Module):
+    """Bias-free deformable convolution v1 with externally supplied offsets (dcn/deform_conv.py:190-236)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super().__init__()
+        assert not bias and groups == 1
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *self.kernel_size))
+        bound = 1.0 / float(np.sqrt(in_channels * self.kernel_size[0] * self.kernel_size[1]))
+        nn.init.uniform_(self.weight, -bound, bound)
+
+    def forward(self, x, offset):
+        return ops.deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                               self.deformable_groups)
+
+
+class AdaptiveConv(nn.Module):
+    """3x3 deformable convolution whose offsets come from predicted boxes, [N, H*W, 18] (ocean_fusion.py:174-192)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = DeformConv(in_channels, out_channels, 3, padding=1)
+
+    def forward(self, x, offset):
+        N, _, H, W = x.shape
+        assert offset is not None and H * W == offset.shape[1]
+        return self.conv(x, offset.permute(0, 2, 1).reshape(N, -1, H, W))
+
+
+class AlignHead(nn.Module):
+    """Classification on box-aligned features: adaptive convolution, ReLU, 1x1 convolution (ocean_fusion.py:195-208)."""
+
+    def __init__(self, in_channels, feat_channels):
+        super().__init__()
+        self.rpn_conv = AdaptiveConv(in_channels, feat_channels)
+        self.rpn_cls = nn.Conv2d(feat_channels, 1, 1)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x, offset):
+        return ops.conv_general(torch.relu(self.rpn_conv(x, offset)), self.rpn_cls)
+
+
+def fusion_pipeline(connect_model, align_head, xf, zf, grid_x, grid_y, search_size, iou_prediction=True, b_iou=0,
+                    pred_to_img_tag=False):
+    """Correlation head, box decoding, align offsets and aligned classification for neck features xf / zf
+    (ocean_model.py:302-321)."""
+    bbox_pred, cls_pred, _, reg_feature, extra = connect_model(xf, zf, iou_prediction=iou_prediction, batch_iou=b_iou)
+    boxes = pred_to_image(bbox_pred, grid_x, grid_y)
+    offsets = align_offsets(boxes.permute(0, 2, 3, 1).reshape(boxes.shape[0], -1, 4), bbox_pred.shape[2:], search_size)
+    out = {"pred_logits": cls_pred, "pred_boxes": bbox_pred, "align_logits": align_head(reg_feature, offsets)}
+    if iou_prediction and "pred_ious" in extra:
+        out["pred_ious"] = extra["pred_ious"]
+    if pred_to_img_tag:
+        out["bbox_pred_to_img"] = boxes.detach()
+    return out
+
+
 def response_grid(score_size, search_size, stride=8):
     """Centres of the response-map cells on the search patch, as (x [S,S], y [S,S]) float64 arrays: cell (r, c) sits
     at ((c - S//2) stride + search//2, (r - S//2) stride + search//2) (ocean_model.py:79-96)."""

@@ -797,6 +797,97 @@ class ConvIm2colFn(torch.autograd.Function):
         return dx, dw, None, None, None, dbias
 
 
+class DeformConvFn(torch.autograd.Function):
+    """Deformable convolution v1, bias-free, one group (dcn/deform_conv.py:12-110 as the aligned head uses it,
+    ocean_fusion.py:174-192): the bilinearly sampled patch matrix is built by one kernel, after which forward,
+    input-gradient and weight-gradient products are the GEMMs of ConvIm2colFn; one more kernel scatters the patch
+    gradient into the input gradient and reduces it into the offset gradient."""
+
+    @staticmethod
+    def forward(ctx, x, offset, weight, stride, pad, dil, dgroups):
+        x, offset = _chk(x.contiguous()), _chk(offset.contiguous())
+        B, Ci, H, W = x.shape
+        Co, Cw, kh, kw = weight.shape
+        if Cw != Ci:
+            raise RuntimeError("spot_amd: deformable convolution with groups > 1 is not supported")
+        K = Ci * kh * kw
+        Kpad = (K + 31) // 32 * 32
+        Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        if tuple(offset.shape) != (B, dgroups * 2 * kh * kw, Ho, Wo):
+            raise RuntimeError("spot_amd: deformable convolution offsets must be [B, groups*2*kh*kw, Ho, Wo], got %s"
+                               % (tuple(offset.shape),))
+        N = Ho * Wo
+        Np = (N + 31) // 32 * 32
+        dev = x.device
+        cols = torch.empty((B, Kpad, Np), dtype=torch.float32, device=dev)
+        lib.call("spot_deform_im2col_f32", _p(x), _p(offset), _p(cols), B, Ci, H, W, kh, kw, stride, pad, dil, dgroups,
+                 Kpad, Np, _st())
+        if Kpad == K:
+            wp = weight.view(Co, K)
+        else:
+            wp = torch.zeros((Co, Kpad), dtype=torch.float32, device=dev)
+            wp[:, :K] = weight.view(Co, K)
+        y = torch.empty((B, Co, Np), dtype=torch.float32, device=dev)
+        gemm(wp, cols, y, Co, Np, Kpad, transB=True, lda=Kpad, ldb=Np, ldc=Np, batch=B, strideB=Kpad * Np, strideC=Co * Np)
+        if Np != N:
+            y = y[:, :, :N].contiguous()
+        ctx.geo = (B, Ci, H, W, Co, kh, kw, stride, pad, dil, dgroups, K, Kpad, N, Np)
+        ctx.save_for_backward(x, offset, cols if ctx.needs_input_grad[2] else None, wp, weight)
+        ctx.params = (weight,)
+        if ctx.needs_input_grad[2]:
+            _sink_expect(weight)
+        return y.view(B, Co, Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, offset, cols, wp, weight = ctx.saved_tensors
+        (pw,) = ctx.params
+        B, Ci, H, W, Co, kh, kw, stride, pad, dil, dgroups, K, Kpad, N, Np = ctx.geo
+        dev = dy.device
+        if Np != N:
+            dyp = torch.zeros((B, Co, Np), dtype=torch.float32, device=dev)
+            dyp[:, :, :N] = dy.reshape(B, Co, N)
+            dy = dyp
+        else:
+            dy = dy.contiguous()
+        dx = doff = dw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dcols = torch.empty((B, Kpad, Np), dtype=torch.float32, device=dev)
+            gemm(wp, dy, dcols, Kpad, Np, Co, transA=True, transB=True, lda=Kpad, ldb=Np, ldc=Np, batch=B,
+                 strideB=Co * Np, strideC=Kpad * Np)
+            dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            doff = ws = None
+            if ctx.needs_input_grad[1]:
+                doff = torch.empty_like(offset)
+                ws = torch.empty((lib.load().spot_deform_col2im_ws_floats(B, Ci, H, W, kh, kw, stride, pad, dil, dgroups),),
+                                 dtype=torch.float32, device=dev)
+            lib.call("spot_deform_col2im_f32", _p(dcols), _p(x), _p(offset), _p(dx), _p(doff), _p(ws), B, Ci, H, W, kh, kw,
+                     stride, pad, dil, dgroups, Kpad, Np, _st())
+        if ctx.needs_input_grad[2]:
+            sk = _sink(pw)
+            direct = sk is not None and Kpad == K
+            dwp = sk.view(Co, K) if direct else torch.zeros((Co, Kpad), dtype=torch.float32, device=dev)
+            gemm(dy, cols, dwp, Co, Kpad, B * Np, lda=Np, ldb=Np, ldc=Kpad, kseg=Np, segA=Co * Np, segB=Kpad * Np,
+                 splitk=_splitk_for(Co, Kpad, B * Np), accumulate=True)
+            if sk is not None:
+                if not direct:
+                    sk.view(Co, K).add_(dwp[:, :K])
+                _sink_done(pw)
+            else:
+                dw = dwp[:, :K].reshape(weight.shape)
+        return dx, doff, dw, None, None, None, None
+
+
+def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+    """Drop-in for dcn.deform_conv (deform_conv.py:186) for square stride / padding / dilation and groups = 1."""
+    one = lambda v: v if isinstance(v, int) else (v[0] if v[0] == v[1] else None)
+    stride, padding, dilation = one(stride), one(padding), one(dilation)
+    if groups != 1 or None in (stride, padding, dilation):
+        raise RuntimeError("spot_amd: deformable convolution supports groups = 1 and square stride / padding / dilation")
+    return DeformConvFn.apply(x, offset, weight, stride, padding, dilation, deformable_groups)
+
+
 OWN_CONV_IM2COL = os.environ.get("SPOT_OWN_CONV_IM2COL", "1") == "1"
 
 

@@ -217,3 +217,68 @@ def test_ocean_criterion_golden(ops, golden):
     assert float(crit.loss_cls({"pred_logits_sup": lg, "cls_label_sup": none}, None, "sup")["loss_ce"]) == 0.0
     lb, iou = crit.add_iouloss(pred[:1], reg[:1], torch.zeros_like(reg_w[:1]), return_iou=True)
     assert float(lb.detach()) == 0.0 and float(iou.detach()) == 0.0
+
+
+@pytest.mark.parametrize("hw,C,Co,dg", [((25, 25), 16, 12, 1), ((9, 13), 8, 5, 2), ((16, 16), 32, 32, 1)])
+def test_deform_conv_matches_oracle(ops, hw, C, Co, dg):
+    """Deformable convolution v1: forward, input, offset and weight gradients against the float64 restatement, with
+    offsets that reach outside the map (samples beyond one pixel outside are zero) and several deformable groups.
+    Parity is against the restated algorithm only: the reference holds no fixture for this operator."""
+    B, H, W = 3, hw[0], hw[1]
+    x = T(det_input("x", (B, C, H, W), 11, -1, 1))
+    off = T(det_input("off", (B, dg * 18, H, W), 12, -3, 3))
+    off[0, :, 0, 0] = 40.0                      # far outside
+    off[1, 0::2, 2, 3] = -30.0
+    off = off + 1e-3                            # keep sample points off the pixel rows / columns (kinks of the bilinear map)
+    w = T(det_input("w", (Co, C, 3, 3), 13, -0.3, 0.3))
+    up = T(det_input("up", (B, Co, H, W), 14, -1, 1))
+    xr, orf, wr = (t.double().requires_grad_() for t in (x, off, w))
+    yr = O.deform_conv(xr, orf, wr, 1, 1, 1, dg)
+    (yr * up.double()).sum().backward()
+    xg, og, wg = (t.to(DEV).requires_grad_() for t in (x, off, w))
+    y = ops.deform_conv(xg, og, wg, 1, 1, 1, 1, dg)
+    (y * up.to(DEV)).sum().backward()
+    _close(y, yr.detach().numpy(), 3e-6, "y")
+    _close(xg.grad, xr.grad.numpy(), 3e-6, "dx")
+    _close(og.grad, orf.grad.numpy(), 1e-5, "doffset")
+    _close(wg.grad, wr.grad.numpy(), 3e-6, "dw")
+    assert float(og.grad[0, :, 0, 0].abs().max()) == 0.0          # invalid samples carry no gradient
+
+
+def test_align_head_and_fusion_pipeline(ops, golden):
+    """The aligned head on the golden tower outputs: zero offsets make the deformable convolution an ordinary 3x3
+    convolution; the whole pipeline (tower, box decoding, offsets, aligned head) equals the oracle's composition and
+    carries gradients back into the regression branch through the offsets."""
+    from spot_amd import ocean
+    g = golden("g17_ocean")
+    neck, tower, xf, zf = _head(g)
+    B, Ch, S = int(g["dims"][0]), int(g["dims"][2]), int(g["dims"][3])
+    head = det_fill_positive_norm_(ocean.AlignHead(Ch, Ch), 77).to(DEV)
+    feat = G(g["eval_reg_feat"])
+    with torch.no_grad():
+        zero = torch.zeros(B, S * S, 18, device=DEV)
+        plain = F.conv2d(torch.relu(F.conv2d(feat, head.rpn_conv.conv.weight, padding=1)), head.rpn_cls.weight, head.rpn_cls.bias)
+        _close(head(feat, zero), plain.cpu().numpy(), 3e-6, "zero offsets")
+    neck.eval(), tower.train()
+    gx, gy = (torch.tensor(a, dtype=torch.float32) for a in ocean.response_grid(S, 255))
+    with torch.no_grad():
+        _, z = neck(zf, crop=True)
+        x = neck(xf, crop=False)
+    out = ocean.fusion_pipeline(tower, head, x, z, gx, gy, 255, iou_prediction=True, b_iou=B, pred_to_img_tag=True)
+    assert set(out) == {"pred_logits", "pred_boxes", "align_logits", "pred_ious", "bbox_pred_to_img"}
+    assert out["align_logits"].shape == (B, 1, S, S)
+    sd = {k: v.detach().cpu().double() for k, v in tower.state_dict().items()}
+    # the oracle's train-mode pass updates running statistics in its own copy; feed it the pre-update values
+    ref_boxes = O.ocean_pred_to_image(out["pred_boxes"].detach().cpu(), 255)
+    np.testing.assert_allclose(out["bbox_pred_to_img"].cpu().numpy(), ref_boxes.numpy(), rtol=0, atol=1e-4)
+    offs = O.ocean_align_offsets(ref_boxes.permute(0, 2, 3, 1).reshape(B, -1, 4), (S, S), 255)
+    hw = {k: v.detach().cpu().double() for k, v in head.state_dict().items()}
+    # reg_feature is the tower's fourth output; recompute it for the oracle from the same parameters
+    with torch.no_grad():
+        _, _, _, reg_feat, _ = tower(x, z, iou_prediction=False)
+    a = O.deform_conv(reg_feat.cpu().double(), offs.double().permute(0, 2, 1).reshape(B, 18, S, S), hw["rpn_conv.conv.weight"], 1, 1, 1)
+    want = F.conv2d(torch.relu(a), hw["rpn_cls.weight"], hw["rpn_cls.bias"])
+    _close(out["align_logits"], want.numpy(), 2e-4, "align logits")
+    out["align_logits"].sum().backward()
+    assert float(tower.bbox_pred.weight.grad.abs().max()) > 0        # through the offsets into the regression head
+    assert float(tower.cls_pred.weight.grad.abs().max() if tower.cls_pred.weight.grad is not None else 0.0) == 0.0
