@@ -342,6 +342,23 @@ int spot_deform_col2im_f32(const float* dcols, const float* x, const float* offs
                            int B, int C, int H, int W, int kh, int kw, int stride, int pad, int dilation,
                            int deformable_groups, int Kpad, int pitch, hipStream_t stream);
 
+/* ---- Crop + pad + resize of a frame on the device (pysot_toolkit/trackers/transt_tracker.py:41-101 get_subwindow,
+ * ltr/data/processing_utils.py:8-91 sample_target: numpy slicing + cv2.resize on the host there).  The frame is uint8
+ * HWC in device memory; the window [y0, y0+crop) x [x0, x0+crop) (x0 / y0 = the reference's context_xmin / ymin, may
+ * be negative) is filled with `pad` where it leaves the frame and resized to out_sz x out_sz, written uint8 CHW
+ * [3, out_sz, out_sz].  crop == out_sz copies; crop == 2 out_sz is the 2x2 box average; anything else OpenCV's 8-bit
+ * INTER_LINEAR arithmetic (weights in 1/2048, see csrc/crop.hip).  The batch form reads B descriptors from device
+ * memory and writes [B, 3, out_sz, out_sz]: one launch for a loader's batch. */
+typedef struct spot_crop_desc {
+    const unsigned char* image;   /* [H, W, 3] */
+    int H, W;
+    int x0, y0;                   /* top-left corner of the window in frame coordinates */
+    int crop;                     /* side of the window */
+    unsigned char pad[4];         /* fill colour per channel (4th byte unused) */
+} spot_crop_desc;
+int spot_crop_resize_u8(const spot_crop_desc* crop /* host */, unsigned char* out, int out_sz, hipStream_t stream);
+int spot_crop_resize_batch_u8(const spot_crop_desc* table_dev, int B, unsigned char* out, int out_sz, hipStream_t stream);
+
 /* ---- Training labels of the Siamese (Ocean) head for B boxes (x, y, w, h on the search patch), one launch
  * (ltr/models/loss/ocean_label_gen.py:44-66,124-233).  S = response-map side, cell (r, c) is centred at
  * ((c - S/2) stride + search_sz/2, (r - S/2) stride + search_sz/2).  Any output may be NULL.

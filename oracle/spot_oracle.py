@@ -730,3 +730,60 @@ def deform_conv(x, offset, weight, stride=1, pad=0, dil=1, dgroups=1):
         groups.append(torch.stack(taps, 2))                      # [B, cpg, taps, N]
     cols = torch.cat(groups, 1).reshape(B, C * kh * kw, Ho * Wo)
     return (weight.reshape(Co, -1) @ cols).reshape(B, Co, Ho, Wo)
+
+
+# --------------------------------------------------------------------------
+# crop + pad + resize (pysot_toolkit/trackers/transt_tracker.py:41-101; ltr/data/processing_utils.py:8-91)
+# The window / padding part restates the reference line by line.  The resize part restates OpenCV's 8-bit
+# INTER_LINEAR (and its 2:1 box-average substitution): PARITY UNPINNED for it, cv2 is not installed here and the
+# reference holds no resized fixture.
+# --------------------------------------------------------------------------
+def crop_window(im, pos, original_sz, avg_chans):
+    """The reference's padded window before any resize: uint8 [sz, sz, 3], plus its (x0, y0) in frame coordinates."""
+    sz = original_sz
+    r, c_, k = im.shape
+    c = (original_sz + 1) / 2
+    xmin = np.floor(pos[0] - c + 0.5)
+    ymin = np.floor(pos[1] - c + 0.5)
+    xmax, ymax = xmin + sz - 1, ymin + sz - 1
+    left, top = int(max(0., -xmin)), int(max(0., -ymin))
+    right, bottom = int(max(0., xmax - c_ + 1)), int(max(0., ymax - r + 1))
+    te = np.zeros((r + top + bottom, c_ + left + right, k), np.uint8)
+    te[top:top + r, left:left + c_, :] = im
+    if top:
+        te[0:top, left:left + c_, :] = avg_chans
+    if bottom:
+        te[r + top:, left:left + c_, :] = avg_chans
+    if left:
+        te[:, 0:left, :] = avg_chans
+    if right:
+        te[:, c_ + left:, :] = avg_chans
+    patch = te[int(ymin + top):int(ymax + top + 1), int(xmin + left):int(xmax + left + 1), :]
+    return patch, int(xmin), int(ymin)
+
+
+def resize_linear_u8(patch, S):
+    """uint8 [n, n, 3] -> [S, S, 3] by OpenCV's fixed-point bilinear rule (see the section header)."""
+    n = patch.shape[0]
+    if n == S:
+        return patch.copy()
+    p = patch.astype(np.int64)
+    if n == 2 * S:
+        return ((p[0::2, 0::2] + p[0::2, 1::2] + p[1::2, 0::2] + p[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    scale = n / S
+    d = np.arange(S, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    fx, sx = f.copy(), s.copy()
+    fx[sx < 0], sx[sx < 0] = 0, 0
+    fx[sx >= n - 1], sx[sx >= n - 1] = 0, n - 1
+    ax0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int64)
+    ax1 = np.rint(fx * np.float32(2048)).astype(np.int64)
+    sx1 = np.minimum(sx + 1, n - 1)
+    ay0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+    ay1 = np.rint(f * np.float32(2048)).astype(np.int64)
+    sy0, sy1 = np.clip(s, 0, n - 1), np.clip(s + 1, 0, n - 1)
+    rows = p[:, sx] * ax0[None, :, None] + p[:, sx1] * ax1[None, :, None]             # [n, S, 3]
+    out = (((ay0[:, None, None] * (rows[sy0] >> 4)) >> 16) + ((ay1[:, None, None] * (rows[sy1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)

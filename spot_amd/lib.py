@@ -37,6 +37,12 @@ class GemmDesc(C.Structure):
     ]
 
 
+class CropDesc(C.Structure):
+    """spot_crop_desc of include/spot_hip.h."""
+    _fields_ = [("image", C.c_void_p), ("H", C.c_int), ("W", C.c_int), ("x0", C.c_int), ("y0", C.c_int),
+                ("crop", C.c_int), ("pad", C.c_ubyte * 4)]
+
+
 class WinogradOpts(C.Structure):
     """Mirror of ``spot_winograd_opts``."""
     _fields_ = [("v_keep", vp), ("u_keep", vp), ("u_valid", i32), ("bn_gamma", vp), ("bn_beta", vp), ("bn_mean", vp),
@@ -75,6 +81,8 @@ SIGNATURES = {
     "spot_ellipse_rotate_boxes_f32": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "spot_channel_scale_f32": [vp, vp, i64, i32, vp],
     "spot_ocean_labels_f32": [vp] * 5 + [i32] * 4 + [f32, i32, vp],
+    "spot_crop_resize_u8": [vp, vp, i32, vp],
+    "spot_crop_resize_batch_u8": [vp, i32, vp, i32, vp],
     "spot_deform_im2col_f32": [vp] * 3 + [i32] * 12 + [vp],
     "spot_deform_col2im_f32": [vp] * 6 + [i32] * 12 + [vp],
     "spot_maxpool3x3s2_fwd_f32": [vp, vp, vp, i64, i32, i32, vp],

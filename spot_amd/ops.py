@@ -223,6 +223,44 @@ class GIoUPairFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------
+# crop + pad + resize of frames
+# ---------------------------------------------------------------------------
+def _crop_desc(frame, x0, y0, crop, pad):
+    assert frame.is_cuda and frame.dtype == torch.uint8 and frame.dim() == 3 and frame.shape[2] == 3 and frame.is_contiguous()
+    d = lib.CropDesc()
+    d.image, d.H, d.W = frame.data_ptr(), frame.shape[0], frame.shape[1]
+    d.x0, d.y0, d.crop = int(x0), int(y0), int(crop)
+    for i in range(3):
+        d.pad[i] = int(pad[i])
+    return d
+
+
+def crop_resize_u8(frame, x0, y0, crop, out_sz, pad):
+    """Window [y0, y0+crop) x [x0, x0+crop) of a uint8 HWC device frame, `pad` outside the frame, resized to
+    out_sz: uint8 [1, 3, out_sz, out_sz] (get_subwindow / sample_target of the reference, on the device)."""
+    out = torch.empty((1, 3, out_sz, out_sz), dtype=torch.uint8, device=frame.device)
+    d = _crop_desc(frame, x0, y0, crop, pad)
+    lib.call("spot_crop_resize_u8", C.byref(d), _p(out), int(out_sz), _st())
+    return out
+
+
+def crop_resize_batch_u8(frames, windows, pads, out_sz):
+    """One launch for a batch: frames[i] (uint8 HWC device tensors of any sizes), windows[i] = (x0, y0, crop),
+    pads[i] = fill colour -> uint8 [B, 3, out_sz, out_sz]."""
+    B = len(frames)
+    dev = frames[0].device if B else "cuda"
+    out = torch.empty((B, 3, out_sz, out_sz), dtype=torch.uint8, device=dev)
+    if B == 0:
+        return out
+    arr = (lib.CropDesc * B)()
+    for i, (f, (x0, y0, crop), pad) in enumerate(zip(frames, windows, pads)):
+        arr[i] = _crop_desc(f, x0, y0, crop, pad)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    lib.call("spot_crop_resize_batch_u8", _p(table), B, _p(out), int(out_sz), _st())
+    return out
+
+
+# ---------------------------------------------------------------------------
 # depthwise cross-correlation
 # ---------------------------------------------------------------------------
 class XCorrDepthwiseFn(torch.autograd.Function):

@@ -66,6 +66,9 @@ class NetWithBackbone:
             return self.net.track(x)
 
 
+GPU_CROP = os.environ.get("SPOT_GPU_CROP", "1") == "1"
+
+
 class TransT_Tracker(object):
     def __init__(self, name, net, window_penalty=0.49, exemplar_size=128, instance_size=256, use_graph=None):
         self.name = name
@@ -96,16 +99,22 @@ class TransT_Tracker(object):
         return cx, cy, width, height
 
     def get_subwindow(self, im, pos, model_sz, original_sz, avg_chans):
-        """Square crop of side original_sz around pos, padded with the channel average
-        (transt_tracker.py:41-101); returned as a uint8 [1,3,model_sz,model_sz] device tensor."""
+        """Square crop of side original_sz around pos, padded with the channel average and resized to model_sz
+        (transt_tracker.py:41-101); returned as a uint8 [1,3,model_sz,model_sz] device tensor.  The window is cut,
+        padded and resized by one kernel from the frame in device memory (`im` may already be a uint8 HWC CUDA
+        tensor; a numpy frame is uploaded once per frame); SPOT_GPU_CROP=0 cuts and pads on the host instead and
+        resizes with the framework's bilinear filter."""
         if isinstance(pos, float):
             pos = [pos, pos]
-        sz = original_sz
-        im_sz = im.shape
+        sz = int(original_sz)
         c = (original_sz + 1) / 2
         context_xmin = np.floor(pos[0] - c + 0.5)
-        context_xmax = context_xmin + sz - 1
         context_ymin = np.floor(pos[1] - c + 0.5)
+        if GPU_CROP or torch.is_tensor(im):
+            pad = np.asarray(avg_chans, dtype=np.float64).astype(np.uint8)        # numpy's cast on assignment
+            return ops.crop_resize_u8(self._device_frame(im), int(context_xmin), int(context_ymin), sz, int(model_sz), pad)
+        im_sz = im.shape
+        context_xmax = context_xmin + sz - 1
         context_ymax = context_ymin + sz - 1
         left_pad = int(max(0., -context_xmin))
         top_pad = int(max(0., -context_ymin))
@@ -134,6 +143,16 @@ class TransT_Tracker(object):
             t = t.round().clamp(0, 255).to(torch.uint8)
         return t.contiguous()
 
+    def _device_frame(self, im):
+        """The frame as a uint8 HWC device tensor; a host frame is uploaded once and remembered while it is the
+        current one (initialize and track both cut from it)."""
+        if torch.is_tensor(im):
+            return im if im.is_cuda else im.cuda()
+        held = getattr(self, "_frame", None)
+        if held is None or held[0] is not im:
+            self._frame = held = (im, torch.from_numpy(np.ascontiguousarray(im)).cuda(non_blocking=True))
+        return held[1]
+
     def _normalize(self, crop_u8):
         return ops.preprocess_u8(crop_u8, None, self.mean, self.std)
 
@@ -154,7 +173,8 @@ class TransT_Tracker(object):
         w_z = self.size[0] + (2 - 1) * ((self.size[0] + self.size[1]) * 0.5)
         h_z = self.size[1] + (2 - 1) * ((self.size[0] + self.size[1]) * 0.5)
         s_z = math.ceil(math.sqrt(w_z * h_z))
-        self.channel_average = np.mean(image, axis=(0, 1))
+        self.channel_average = (image.float().mean(dim=(0, 1)).cpu().numpy() if torch.is_tensor(image)
+                                else np.mean(image, axis=(0, 1)))
         z_crop = self.get_subwindow(image, self.center_pos, self.exemplar_size, s_z, self.channel_average)
         self.net.template(self._normalize(z_crop))
         self._graph, self._eager_frames = None, 0       # the captured graph reads the previous template's features

@@ -33,6 +33,7 @@ How the reference is imported (all CPU, torch 2.x):
 Usage:  python tests/golden/make_golden.py [case ...]
 """
 import importlib.util
+import math
 import os
 import sys
 import types
@@ -626,6 +627,41 @@ def case_transforms(seed=97):
          gray_img=t2n(groups[1]), gray_avg_t=t2n(avgs[0]), gray_avg=t2n(avgs[1]))
 
 
+def case_crop(seed=41):
+    """G18: the reference's crop windows without resize (cv2 is absent, so only calls whose crop side equals the
+    output side are possible): TransT_Tracker.get_subwindow and processing_utils.sample_target on a seeded frame,
+    windows inside the frame and leaving it on every side."""
+    from pysot_toolkit.trackers.transt_tracker import TransT_Tracker
+    import ltr.data.processing_utils as prutils
+    im = det_input("frame", (120, 160, 3), seed, 0, 256, np.uint8)
+    avg = np.mean(im, axis=(0, 1))
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    out = {"avg": avg}
+    try:
+        stub = types.SimpleNamespace()
+        cases = [((80.0, 60.0), 64), ((5.0, 7.5), 48), ((158.2, 118.9), 51), ((80.5, 60.5), 200), ((-30.0, 50.0), 40),
+                 ((10.25, 110.75), 33)]
+        for i, (pos, sz) in enumerate(cases):
+            t = TransT_Tracker.get_subwindow(stub, im, np.array(pos), sz, sz, avg)
+            out["sub%d" % i] = t.numpy().astype(np.uint8)
+        out["sub_pos"] = np.array([c[0] for c in cases])
+        out["sub_sz"] = np.array([c[1] for c in cases])
+        boxes = [[60.0, 40.0, 30.0, 20.0], [2.0, 3.0, 25.0, 31.0], [140.0, 100.0, 22.0, 18.0]]
+        szs = []
+        for i, bb in enumerate(boxes):
+            w, h = bb[2], bb[3]
+            crop_sz = math.ceil(math.sqrt((w + (w + h) * 0.5) * (h + (w + h) * 0.5)))
+            patch, rf = prutils.sample_target(im, torch.tensor(bb), 2.0, output_sz=crop_sz, avg=avg)
+            assert rf == 1.0
+            out["st%d" % i] = np.ascontiguousarray(patch)
+            szs.append(crop_sz)
+        out["st_boxes"], out["st_sz"] = np.array(boxes), np.array(szs)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    save("g18_crop", seed=seed, **out)
+
+
 def case_ocean(seed=23):
     """G17: the Siamese head around the correlation: neck, box_tower (encoders, correlation, towers, heads) forward
     and gradients in train mode, forward in eval mode, pred_to_image / offsets, label generator, criterion."""
@@ -785,7 +821,7 @@ CASES = {
     "decode": case_decode, "compaction": case_compaction, "boxes": case_boxes,
     "matcher_criterion": case_matcher_criterion, "tracker_post": case_tracker_post,
     "xcorr": case_xcorr, "ema": case_ema, "pre_pos": case_preprocess_posenc,
-    "student": case_student, "transforms": case_transforms, "ocean": case_ocean,
+    "student": case_student, "transforms": case_transforms, "ocean": case_ocean, "crop": case_crop,
 }
 
 

@@ -342,3 +342,37 @@ def test_g17_ocean_labels_and_losses(golden):
     for got, key in ((pred.grad, "d_pred"), (logits.grad, "d_logits"), (align_logits.grad, "d_align_logits"),
                      (pred_ious.grad, "d_pred_ious")):
         np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-5, atol=1e-9, err_msg=key)
+
+
+def test_g18_crop_windows(golden):
+    """The crop window / padding restated == the reference's get_subwindow and sample_target (calls without resize)."""
+    g = golden("g18_crop")
+    im = det_input("frame", (120, 160, 3), int(g["seed"]), 0, 256, np.uint8)
+    avg = g["avg"]
+    for i, (pos, sz) in enumerate(zip(g["sub_pos"], g["sub_sz"])):
+        patch, _, _ = O.crop_window(im, pos, int(sz), avg)
+        assert np.array_equal(patch.transpose(2, 0, 1)[None], g["sub%d" % i]), i
+        assert np.array_equal(O.resize_linear_u8(patch, int(sz)), patch)
+    for i, (bb, sz) in enumerate(zip(g["st_boxes"], g["st_sz"])):
+        pos = [bb[0] + 0.5 * bb[2], bb[1] + 0.5 * bb[3]]
+        patch, _, _ = O.crop_window(im, pos, int(sz), avg)
+        assert np.array_equal(patch, g["st%d" % i]), i
+
+
+def test_resize_rule_properties():
+    """The fixed-point bilinear restatement: constant images stay constant, a 2:1 reduction is the box average, an
+    integer up-scaling reproduces the source at the sample centres' pixels, outputs stay within the input range."""
+    rng = np.random.default_rng(3)
+    for n, S in ((37, 128), (300, 256), (64, 32), (129, 128), (5, 7)):
+        const = np.full((n, n, 3), 173, np.uint8)
+        assert np.array_equal(O.resize_linear_u8(const, S), np.full((S, S, 3), 173, np.uint8))
+        p = rng.integers(0, 256, (n, n, 3), dtype=np.uint8)
+        r = O.resize_linear_u8(p, S)
+        assert r.shape == (S, S, 3) and r.min() >= p.min() and r.max() <= p.max()
+    p = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    q = p.astype(np.int64)
+    assert np.array_equal(O.resize_linear_u8(p, 32), ((q[0::2, 0::2] + q[0::2, 1::2] + q[1::2, 0::2] + q[1::2, 1::2] + 2) >> 2))
+    ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8)[None, :, None], (100, 1, 3))          # linear in x
+    up = O.resize_linear_u8(ramp, 300).astype(np.int64)
+    want = np.clip(((np.arange(300) + 0.5) / 3 - 0.5), 0, 99) * 2
+    assert np.abs(up[150, :, 0] - want).max() <= 1

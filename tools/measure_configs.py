@@ -41,8 +41,9 @@ def cfg1():
             trk.track(f)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-    print(json.dumps({"config": "cfg1: tracker API, B=1, 49 track() calls on 256x256 frames incl. host crop, "
-                                "H2D, network, device decode, D2H", "value": round(49 / el, 2), "unit": "frames/s",
+    print(json.dumps({"config": "cfg1: tracker API, B=1, 49 track() calls on 256x256 frames incl. " +
+                                ("frame upload, device crop + resize" if __import__("spot_amd.tracker", fromlist=["GPU_CROP"]).GPU_CROP else "host crop, crop upload, resize") +
+                                ", network, device decode, D2H", "value": round(49 / el, 2), "unit": "frames/s",
                       "ms_per_frame": round(el / 49 * 1e3, 3), "graph_replay": trk._graph is not None}))
 
 
