@@ -35,7 +35,8 @@ const char* spot_last_error(void);
 /* NormJitter + Normalize, ltr/models/pre_input/necessary_preprocess.py:54-67,86-91.
  * out = (clamp(float(images) * scale[b], 0, 1) - mean[c]) / std[c].
  * images [B,3,H,W] uint8, scale [B] (brightness/255; NULL = 1/255), mean3/std3 HOST
- * pointers to 3 floats, out [B,3,H,W] float.  H*W must be a multiple of 16. */
+ * pointers to 3 floats, out [B,3,H,W] float.  16 pixels per lane when H*W is a multiple of 16 and both buffers are
+ * 16-byte aligned, one otherwise (255x255 and 127x127 crops). */
 int spot_preprocess_u8_f32(const unsigned char* images, const float* scale, const float* mean3,
                            const float* std3, float* out, int B, int C, int H, int W, hipStream_t stream);
 
@@ -249,7 +250,7 @@ int spot_rotate_flip_nearest_f32(const float* in, float* out, const float* theta
  * box; all outputs are clamped at 0. */
 int spot_ellipse_rotate_boxes_f32(const float* bbox, const float* angle, const unsigned char* lr_flip,
                                   const unsigned char* apply, float* out, int B, int W, int H, hipStream_t stream);
-/* x[p][:] *= scale[p] for planes p of HW floats (HW a multiple of 4), in place: the per-channel weighting of
+/* x[p][:] *= scale[p] for planes p of HW floats, in place (16-byte accesses when HW is a multiple of 4): the per-channel weighting of
  * GrayScale.forward (:384-396) with scale = colour weight or 1 per (sample, channel). */
 int spot_channel_scale_f32(float* x, const float* scale, long planes, int HW, hipStream_t stream);
 

@@ -787,3 +787,16 @@ def resize_linear_u8(patch, S):
     rows = p[:, sx] * ax0[None, :, None] + p[:, sx1] * ax1[None, :, None]             # [n, S, 3]
     out = (((ay0[:, None, None] * (rows[sy0] >> 4)) >> 16) + ((ay1[:, None, None] * (rows[sy1] >> 4)) >> 16) + 2) >> 2
     return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def ocean_decode_teacher(pred_logits, align_logits, pred_ious, boxes_xyxy, cls_ratio, window_penalty):
+    """ltr/actor/ocean_sparse_actor.py:40-94: score mix, Hanning penalty, arg-max cell -> (xywh box, score, IoU)."""
+    B, S = pred_logits.shape[0], pred_logits.shape[-1]
+    score = cls_ratio * torch.sigmoid(pred_logits) + (1 - cls_ratio) * torch.sigmoid(align_logits)
+    h = torch.tensor(np.hanning(S), dtype=score.dtype)
+    score = (window_penalty * torch.outer(h, h)[None, None] + (1 - window_penalty) * score).reshape(B, -1)
+    best, idx = score.max(1)
+    b = boxes_xyxy.reshape(B, 4, -1).transpose(1, 2)[torch.arange(B), idx]
+    xywh = torch.stack([b[:, 0].clamp_min(0), b[:, 1].clamp_min(0), (b[:, 2] - b[:, 0]).clamp_min(1),
+                        (b[:, 3] - b[:, 1]).clamp_min(1)], 1)
+    return xywh, best, pred_ious.reshape(B, -1)[torch.arange(B), idx]

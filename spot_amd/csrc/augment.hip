@@ -98,6 +98,14 @@ __global__ __launch_bounds__(256) void channel_scale_kernel(float* __restrict__ 
     reinterpret_cast<float4*>(x)[i] = v;
 }
 
+// element by element, for planes whose size is not a multiple of 4 (255x255 and 127x127 crops)
+__global__ __launch_bounds__(256) void channel_scale_scalar_kernel(float* __restrict__ x, const float* __restrict__ scale,
+                                                                   long planes, int HW) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= planes * HW) return;
+    x[i] *= scale[i / HW];
+}
+
 }  // namespace
 
 extern "C" int spot_rotate_flip_nearest_f32(const float* in, float* out, const float* theta_table, const float* angle,
@@ -126,11 +134,13 @@ extern "C" int spot_ellipse_rotate_boxes_f32(const float* bbox, const float* ang
 
 extern "C" int spot_channel_scale_f32(float* x, const float* scale, long planes, int HW, hipStream_t stream) {
     SPOT_CHECK_ARG(x && scale, "channel_scale: null pointer");
-    SPOT_CHECK_ARG(planes >= 0 && HW > 0 && HW % 4 == 0 && ((uintptr_t)x & 15) == 0, "channel_scale: HW=%d must be a multiple of 4, x 16-byte aligned", HW);
+    SPOT_CHECK_ARG(planes >= 0 && HW > 0, "channel_scale: bad shape HW=%d", HW);
     if (planes == 0) return SPOT_OK;
-    const long n = planes * (HW / 4);
+    const bool vec = HW % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    const long n = vec ? planes * (HW / 4) : planes * (long)HW;
     SPOT_CHECK_ARG((n + 255) / 256 < (1L << 31), "channel_scale: too large");
-    channel_scale_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(x, scale, planes, HW / 4);
+    if (vec) channel_scale_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(x, scale, planes, HW / 4);
+    else channel_scale_scalar_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(x, scale, planes, HW);
     SPOT_CHECK_LAUNCH("channel_scale");
     return SPOT_OK;
 }

@@ -38,6 +38,22 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint4* __restrict
     }
 }
 
+// The same map one byte per lane, for crops whose pixel count is not a multiple of 16 (the Siamese variant's 255^2
+// and 127^2 crops, ltr/train_settings/spot/spot_ocean_003.py:86-87).
+__global__ __launch_bounds__(256) void preprocess_bytes_kernel(const unsigned char* __restrict__ img,
+                                                               const float* __restrict__ scale, float3 mean, float3 stdv,
+                                                               float* __restrict__ out, long plane_px, int C, long total) {
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long)gridDim.x * 256) {
+        const long plane = v / plane_px;
+        const int c = (int)(plane % C);
+        const int b = (int)(plane / C);
+        const float s = scale ? scale[b] : (1.0f / 255.0f);
+        const float m = c == 0 ? mean.x : (c == 1 ? mean.y : mean.z);
+        const float d = c == 0 ? stdv.x : (c == 1 ? stdv.y : stdv.z);
+        out[v] = __fdiv_rn(__fsub_rn(fminf(fmaxf(__fmul_rn((float)img[v], s), 0.f), 1.f), m), d);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // teacher EMA (ltr/actor/transt_sparse_actor.py:11-33) on flat parameter storage
 //   t = s * (1 - keep) + t * keep      (two rounded products, one rounded sum)
@@ -212,9 +228,16 @@ extern "C" int spot_preprocess_u8_f32(const unsigned char* images, const float* 
     SPOT_CHECK_ARG(images && out && mean3 && std3, "preprocess: null pointer");
     SPOT_CHECK_ARG(B >= 0 && C == 3 && H > 0 && W > 0, "preprocess: bad shape B=%d C=%d H=%d W=%d (C must be 3)", B, C,
                    H, W);
-    SPOT_CHECK_ARG(((long)H * W) % 16 == 0, "preprocess: H*W=%ld must be a multiple of 16", (long)H * W);
-    SPOT_CHECK_ARG((uintptr_t)images % 16 == 0 && (uintptr_t)out % 16 == 0, "preprocess: buffers must be 16-byte aligned");
     if (B == 0) return SPOT_OK;
+    if (((long)H * W) % 16 != 0 || (uintptr_t)images % 16 != 0 || (uintptr_t)out % 16 != 0) {
+        const long total = (long)H * W * C * B;
+        int grid = spot_ceil_div(total, 256);
+        if (grid > 65535) grid = 65535;
+        preprocess_bytes_kernel<<<grid, 256, 0, stream>>>(images, scale, make_float3(mean3[0], mean3[1], mean3[2]),
+                                                          make_float3(std3[0], std3[1], std3[2]), out, (long)H * W, C, total);
+        SPOT_CHECK_LAUNCH("preprocess");
+        return SPOT_OK;
+    }
     const long plane_vec = (long)H * W / 16;
     const long total = plane_vec * C * B;
     int grid = (int)((total + 255) / 256);

@@ -662,6 +662,50 @@ def case_crop(seed=41):
     save("g18_crop", seed=seed, **out)
 
 
+def case_ocean_model(seed=29):
+    """G19: the Siamese variant's backbone (ocean_backbone.py) on a 127x127 crop, eval and train mode with gradients,
+    and OceanSparseActor's pseudo-label decoding on seeded teacher outputs."""
+    from ltr.models.backbone.ocean_backbone import ResNet50_Ocean
+    import ltr.actor as actors
+    from ltr.utils import TensorDict
+    out = {}
+    net = det_fill_(ResNet50_Ocean(used_layers=[3]), seed)
+    x = torch.from_numpy(det_input("crop", (2, 3, 127, 127), seed, -2, 2)).requires_grad_()
+    net.eval()
+    with torch.no_grad():
+        stages, p3 = net(x)
+    out.update(eval_p3=t2n(p3[:, ::32]), eval_p2=t2n(stages[2][:, ::64]), eval_stem=t2n(stages[0][:, ::8, ::4, ::4]))
+    net.train()
+    stages, p3 = net(x)
+    up = torch.from_numpy(det_input("up", tuple(p3.shape), seed, -1, 1))
+    (p3 * up).sum().backward()
+    out.update(train_p3=t2n(p3[:, ::32]), d_crop=t2n(x.grad[:, :, ::2, ::2]))
+    params = dict(net.named_parameters())
+    for name in ("features.conv1.weight", "features.layer1.0.downsample.0.weight", "features.layer2.0.conv2.weight",
+                 "features.layer2.0.downsample.0.weight", "features.layer3.0.downsample.0.weight",
+                 "features.layer3.2.conv2.weight", "features.layer3.5.bn3.weight", "features.layer2.3.bn1.bias"):
+        g = params[name].grad
+        out["d." + name] = t2n(g.reshape(-1)[::max(1, g.numel() // 4096)])
+    out["running_mean_l3"] = t2n(net.features.layer3[0].bn2.running_mean)
+    out["keys"] = np.array(list(net.state_dict().keys()))
+    # ---- actor decode
+    B, S = 6, 25
+    raw = TensorDict({
+        "pred_logits": torch.from_numpy(det_input("lg", (B, 1, S, S), seed, -4, 4)),
+        "align_logits": torch.from_numpy(det_input("al", (B, 1, S, S), seed, -4, 4)),
+        "pred_ious": torch.from_numpy(det_input("io", (B, 1, S, S), seed, 0, 1)),
+        "bbox_pred_to_img": torch.from_numpy(np.concatenate([det_input("b0", (B, 2, S, S), seed, -20, 120),
+                                                              det_input("b1", (B, 2, S, S), seed, 100, 260)], 1))})
+    raw["bbox_pred_to_img"][0, 2:] = raw["bbox_pred_to_img"][0, :2] + 0.25          # boxes narrower than 1 px: clamped
+    S_ = types.SimpleNamespace(curriculum_settings={"cls_ratio": 0.6, "window_penalty": 0.30}, output_sz=S)
+    teacher = lambda teacher_data=None: raw
+    actor = actors.OceanSparseActor.__new__(actors.OceanSparseActor)
+    actor.settings, actor.teacher_net = S_, teacher
+    res = actor._inference_with_teacher(teacher_data=None)
+    out.update(best_bbox=t2n(res["best_bbox"]), best_score=t2n(res["best_score"]), best_conf=t2n(res["best_conf"]))
+    save("g19_ocean_model", seed=seed, **out)
+
+
 def case_ocean(seed=23):
     """G17: the Siamese head around the correlation: neck, box_tower (encoders, correlation, towers, heads) forward
     and gradients in train mode, forward in eval mode, pred_to_image / offsets, label generator, criterion."""
@@ -821,7 +865,7 @@ CASES = {
     "decode": case_decode, "compaction": case_compaction, "boxes": case_boxes,
     "matcher_criterion": case_matcher_criterion, "tracker_post": case_tracker_post,
     "xcorr": case_xcorr, "ema": case_ema, "pre_pos": case_preprocess_posenc,
-    "student": case_student, "transforms": case_transforms, "ocean": case_ocean, "crop": case_crop,
+    "student": case_student, "transforms": case_transforms, "ocean": case_ocean, "ocean_model": case_ocean_model, "crop": case_crop,
 }
 
 

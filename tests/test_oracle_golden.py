@@ -376,3 +376,17 @@ def test_resize_rule_properties():
     up = O.resize_linear_u8(ramp, 300).astype(np.int64)
     want = np.clip(((np.arange(300) + 0.5) / 3 - 0.5), 0, 99) * 2
     assert np.abs(up[150, :, 0] - want).max() <= 1
+
+
+def test_g19_ocean_actor_decode(golden):
+    """OceanSparseActor's pseudo-label decoding restated == the reference's (ocean_sparse_actor.py:40-94)."""
+    g = golden("g19_ocean_model")
+    seed, B, S = int(g["seed"]), 6, 25
+    lg, al, io = (T(det_input(n, (B, 1, S, S), seed, lo, hi)) for n, lo, hi in (("lg", -4, 4), ("al", -4, 4), ("io", 0, 1)))
+    boxes = T(np.concatenate([det_input("b0", (B, 2, S, S), seed, -20, 120), det_input("b1", (B, 2, S, S), seed, 100, 260)], 1))
+    boxes[0, 2:] = boxes[0, :2] + 0.25
+    bbox, score, conf = O.ocean_decode_teacher(lg, al, io, boxes, 0.6, 0.30)
+    np.testing.assert_allclose(bbox.numpy(), g["best_bbox"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(score.numpy(), g["best_score"], rtol=1e-6)
+    np.testing.assert_allclose(conf.numpy(), g["best_conf"], rtol=0, atol=0)
+    assert (g["best_bbox"][0, 2:] == 1.0).all()
