@@ -370,6 +370,14 @@ int spot_crop_resize_batch_u8(const spot_crop_desc* table_dev, int B, unsigned c
 int spot_ocean_labels_f32(const float* anno_xywh, float* cls, double* reg, float* reg_w, float* iou_w, int B, int S,
                           int stride, int search_sz, float expand, int radius, hipStream_t stream);
 
+/* One frame of the Siamese online tracker (pysot_toolkit/trackers/ocean_tracker.py:71-104): from the classification
+ * and align logits [S,S], the ltrb map [4,S,S], the float64 cosine window [S,S] and the target size scaled to the
+ * crop, the winning cell after score mixing (ratio), scale / aspect penalty (penalty_k) and window blend
+ * (window_influence).  out8 (device, float64) = (row, col, x1, y1, x2, y2, penalty, mixed score) of that cell. */
+int spot_ocean_tracker_decode(const float* cls_logits, const float* align_logits, const float* ltrb, const double* window,
+                              double target_w, double target_h, double ratio, double penalty_k, double window_influence,
+                              int S, int stride, int instance_size, double* out8, hipStream_t stream);
+
 /* ---- BatchNorm2d fused with the ReLU / residual add that follow it in the ResNet bottleneck
  * (ltr/models/backbone/resnet.py:72-92,196-198; the Siamese head's conv-bn-relu stacks,
  * ltr/models/neck/ocean_fusion.py:56-85,126-158), NCHW fp32.  Planes are walked in packs of four floats when HW is a

@@ -800,3 +800,32 @@ def ocean_decode_teacher(pred_logits, align_logits, pred_ious, boxes_xyxy, cls_r
     xywh = torch.stack([b[:, 0].clamp_min(0), b[:, 1].clamp_min(0), (b[:, 2] - b[:, 0]).clamp_min(1),
                         (b[:, 3] - b[:, 1]).clamp_min(1)], 1)
     return xywh, best, pred_ious.reshape(B, -1)[torch.arange(B), idx]
+
+
+def ocean_tracker_update(cls, ltrb, align, target_pos, target_sz, window, scale_z, ratio=0.94, penalty_k=0.062,
+                         window_influence=0.38, lr=0.765, stride=8, instance_size=255):
+    """pysot_toolkit/trackers/ocean_tracker.py:71-130 on numpy maps cls / align [S,S] float32, ltrb [4,S,S] float32;
+    target_sz is already scaled by scale_z, as the caller passes it (:155-156)."""
+    S = cls.shape[-1]
+    gx, gy = ocean_grid(S, instance_size, stride)
+    gx, gy = gx.numpy(), gy.numpy()
+    sig = lambda a: (1.0 / (1.0 + np.exp(-a.astype(np.float32)))).astype(np.float32)
+    score = np.float32(ratio) * sig(cls) + np.float32(1 - ratio) * sig(align)
+    x1, y1, x2, y2 = gx - ltrb[0], gy - ltrb[1], gx + ltrb[2], gy + ltrb[3]
+    change = lambda r: np.maximum(r, 1.0 / r)
+
+    def sz(w, h):
+        pad = (w + h) * 0.5
+        return np.sqrt((w + pad) * (h + pad))
+    s_c = change(sz(x2 - x1, y2 - y1) / sz(target_sz[0], target_sz[1]))
+    r_c = change((target_sz[0] / target_sz[1]) / ((x2 - x1) / (y2 - y1)))
+    penalty = np.exp(-(r_c * s_c - 1) * penalty_k)
+    pscore = penalty * score * (1 - window_influence) + window * window_influence
+    r, c = np.unravel_index(pscore.argmax(), pscore.shape)
+    w, h = (x2 - x1)[r, c] / scale_z, (y2 - y1)[r, c] / scale_z
+    dx = ((x1 + x2)[r, c] / 2 - instance_size // 2) / scale_z
+    dy = ((y1 + y2)[r, c] / 2 - instance_size // 2) / scale_z
+    tsz = np.asarray(target_sz, dtype=np.float64) / scale_z
+    rate = penalty[r, c] * score[r, c] * lr
+    res = np.array([w * rate + (1 - rate) * tsz[0], h * rate + (1 - rate) * tsz[1]])
+    return np.array([target_pos[0] + dx, target_pos[1] + dy]), tsz * (1 - rate) + rate * res, score[r, c]

@@ -46,7 +46,84 @@ __global__ __launch_bounds__(256) void ocean_labels_kernel(const float* __restri
     }
 }
 
+// One frame of the Siamese online tracker, from the network's three maps to the winning cell
+// (pysot_toolkit/trackers/ocean_tracker.py:71-104): score = ratio sigmoid(cls) + (1 - ratio) sigmoid(align) in
+// float32; boxes, scale / ratio penalty, window blend and arg-max in float64 like the reference's numpy arithmetic
+// (its grid is float64); the first maximum wins.  out[8] = (row, col, x1, y1, x2, y2, penalty, score) of that cell.
+__global__ __launch_bounds__(256) void ocean_tracker_decode_kernel(const float* __restrict__ cls, const float* __restrict__ align,
+                                                                   const float* __restrict__ ltrb, const double* __restrict__ window,
+                                                                   double tw, double th, float ratio, float one_minus_ratio,
+                                                                   double penalty_k, double window_influence, int S, int stride,
+                                                                   int instance, double* __restrict__ out) {
+    __shared__ double bv[256];
+    __shared__ int bi[256];
+    const int n = S * S;
+    double best = -1.0 / 0.0;
+    int besti = n;
+    const double pad_t = (tw + th) * 0.5, sz_t = sqrt((tw + pad_t) * (th + pad_t));
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = i / S, c = i - r * S;
+        const float sc = ratio * (1.f / (1.f + expf(-cls[i]))) + one_minus_ratio * (1.f / (1.f + expf(-align[i])));
+        const double gx = (double)((c - S / 2) * stride + instance / 2), gy = (double)((r - S / 2) * stride + instance / 2);
+        const double w = (gx + (double)ltrb[2 * n + i]) - (gx - (double)ltrb[i]);
+        const double h = (gy + (double)ltrb[3 * n + i]) - (gy - (double)ltrb[n + i]);
+        const double pad = (w + h) * 0.5;
+        double sc_r = sqrt((w + pad) * (h + pad)) / sz_t;
+        sc_r = fmax(sc_r, 1.0 / sc_r);
+        double rc_r = (tw / th) / (w / h);
+        rc_r = fmax(rc_r, 1.0 / rc_r);
+        const double pen = exp(-(rc_r * sc_r - 1.0) * penalty_k);
+        const double ps = pen * (double)sc * (1.0 - window_influence) + window[i] * window_influence;
+        if (ps > best) {
+            best = ps;
+            besti = i;
+        }
+    }
+    bv[threadIdx.x] = best;
+    bi[threadIdx.x] = besti;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double v = bv[threadIdx.x + o];
+            const int j = bi[threadIdx.x + o];
+            if (v > bv[threadIdx.x] || (v == bv[threadIdx.x] && j < bi[threadIdx.x])) {
+                bv[threadIdx.x] = v;
+                bi[threadIdx.x] = j;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int i = bi[0] < n ? bi[0] : 0, r = i / S, c = i - r * S;
+        const float sc = ratio * (1.f / (1.f + expf(-cls[i]))) + one_minus_ratio * (1.f / (1.f + expf(-align[i])));
+        const double gx = (double)((c - S / 2) * stride + instance / 2), gy = (double)((r - S / 2) * stride + instance / 2);
+        const double x1 = gx - (double)ltrb[i], y1 = gy - (double)ltrb[n + i];
+        const double x2 = gx + (double)ltrb[2 * n + i], y2 = gy + (double)ltrb[3 * n + i];
+        const double w = x2 - x1, h = y2 - y1, pad = (w + h) * 0.5;
+        double sc_r = sqrt((w + pad) * (h + pad)) / sz_t;
+        sc_r = fmax(sc_r, 1.0 / sc_r);
+        double rc_r = (tw / th) / (w / h);
+        rc_r = fmax(rc_r, 1.0 / rc_r);
+        out[0] = r; out[1] = c; out[2] = x1; out[3] = y1; out[4] = x2; out[5] = y2;
+        out[6] = exp(-(rc_r * sc_r - 1.0) * penalty_k);
+        out[7] = (double)sc;
+    }
+}
+
 }  // namespace
+
+extern "C" int spot_ocean_tracker_decode(const float* cls_logits, const float* align_logits, const float* ltrb,
+                                         const double* window, double target_w, double target_h, double ratio,
+                                         double penalty_k, double window_influence, int S, int stride, int instance_size,
+                                         double* out8, hipStream_t stream) {
+    SPOT_CHECK_ARG(cls_logits && align_logits && ltrb && window && out8, "ocean_tracker_decode: null pointer");
+    SPOT_CHECK_ARG(S > 0 && stride > 0 && instance_size > 0, "ocean_tracker_decode: bad shape");
+    ocean_tracker_decode_kernel<<<1, 256, 0, stream>>>(cls_logits, align_logits, ltrb, window, target_w, target_h, (float)ratio,
+                                                       (float)(1.0 - ratio), penalty_k, window_influence, S, stride,
+                                                       instance_size, out8);
+    SPOT_CHECK_LAUNCH("ocean_tracker_decode");
+    return SPOT_OK;
+}
 
 extern "C" int spot_ocean_labels_f32(const float* anno_xywh, float* cls, double* reg, float* reg_w, float* iou_w, int B,
                                      int S, int stride, int search_sz, float expand, int radius, hipStream_t stream) {

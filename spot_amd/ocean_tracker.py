@@ -1,0 +1,142 @@
+"""Online tracker of the Siamese variant (pysot_toolkit/trackers/ocean_tracker.py:11-288) on the HIP kernels: the
+frame is cut, padded and resized on the device, normalised by the preprocess kernel, run through Ocean.track, and
+reduced to the winning cell by one kernel; eight float64 values come back to the host per frame, where the
+reference's scalar box update follows."""
+import time
+
+import numpy as np
+import torch
+
+from . import lib, ops
+
+
+class OceanConfig(object):
+    """ocean_tracker.py:278-288."""
+    penalty_k = 0.062
+    window_influence = 0.38
+    lr = 0.765
+    windowing = "cosine"
+    exemplar_size = 127
+    instance_size = 255
+    total_stride = 8
+    score_size = (instance_size - exemplar_size) // total_stride + 1 + 8
+    context_amount = 0.5
+    ratio = 0.94
+
+
+class Ocean_Tracker(object):
+    def __init__(self, name, net):
+        self.name, self.net = name, net
+        self.p = OceanConfig()
+        self.state = None
+        self.mean, self.std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+    def initialize_features(self):
+        if not getattr(self, "features_initialized", False) and hasattr(self.net, "initialize"):
+            self.net.initialize()
+        self.features_initialized = True
+
+    @staticmethod
+    def python2round(f):
+        """ocean_tracker.py:212-218."""
+        if round(f + 1) - round(f) != 1:
+            return f + abs(f) / f * 0.5
+        return round(f)
+
+    def _device_frame(self, im):
+        if torch.is_tensor(im):
+            return im if im.is_cuda else im.cuda()
+        held = getattr(self, "_frame", None)
+        if held is None or held[0] is not im:
+            self._frame = held = (im, torch.from_numpy(np.ascontiguousarray(im)).cuda(non_blocking=True))
+        return held[1]
+
+    def get_subwindow_tracking(self, im, pos, model_sz, original_sz, avg_chans):
+        """SiamFC-type crop (ocean_tracker.py:225-275; note its window origin is round(pos - c), Python's rounding):
+        uint8 [1, 3, model_sz, model_sz] on the device."""
+        if isinstance(pos, float):
+            pos = [pos, pos]
+        c = (original_sz + 1) / 2
+        x0, y0 = round(pos[0] - c), round(pos[1] - c)
+        pad = np.asarray(avg_chans, dtype=np.float64).astype(np.uint8)
+        return ops.crop_resize_u8(self._device_frame(im), int(x0), int(y0), int(original_sz), int(model_sz), pad)
+
+    def _normalize(self, crop_u8):
+        return ops.preprocess_u8(crop_u8, None, self.mean, self.std)
+
+    def initialize(self, image, info: dict) -> dict:
+        tic = time.time()
+        p = OceanConfig()
+        state = {"im_h": image.shape[0], "im_w": image.shape[1]}
+        self.initialize_features()
+        bbox = info["init_bbox"]
+        target_pos = np.array([bbox[0] + bbox[2] / 2, bbox[1] + bbox[3] / 2])
+        target_sz = np.array([bbox[2], bbox[3]])
+        wc_z = target_sz[0] + p.context_amount * sum(target_sz)
+        hc_z = target_sz[1] + p.context_amount * sum(target_sz)
+        s_z = round(np.sqrt(wc_z * hc_z))
+        avg_chans = (image.float().mean(dim=(0, 1)).cpu().numpy() if torch.is_tensor(image) else np.mean(image, axis=(0, 1)))
+        z_crop = self.get_subwindow_tracking(image, target_pos, p.exemplar_size, s_z, avg_chans)
+        with torch.no_grad():
+            self.net.template(self._normalize(z_crop))
+        if p.windowing == "cosine":
+            window = np.outer(np.hanning(p.score_size), np.hanning(p.score_size))
+        else:
+            window = np.ones((int(p.score_size), int(p.score_size)))
+        self._window_dev = torch.from_numpy(np.ascontiguousarray(window)).cuda()
+        state.update(p=p, net=self.net, avg_chans=avg_chans, window=window, target_pos=target_pos, target_sz=target_sz)
+        self.state = state
+        return {"time": time.time() - tic}
+
+    def decode(self, cls_score, bbox_pred, cls_align, target_sz, p):
+        """Device part of update(): the winning cell as eight float64 values (see spot_ocean_tracker_decode)."""
+        S = int(p.score_size)
+        out = torch.empty((8,), dtype=torch.float64, device=cls_score.device)
+        lib.call("spot_ocean_tracker_decode", ops._p(cls_score.contiguous()), ops._p(cls_align.contiguous()),
+                 ops._p(bbox_pred.contiguous()), ops._p(self._window_dev), float(target_sz[0]), float(target_sz[1]),
+                 float(p.ratio), float(p.penalty_k), float(p.window_influence), S, int(p.total_stride),
+                 int(p.instance_size), ops._p(out), ops._st())
+        return out
+
+    def update(self, net, x_crops, target_pos, target_sz, window, scale_z, p):
+        """ocean_tracker.py:71-130."""
+        with torch.no_grad():
+            cls_score, bbox_pred, cls_align = net.track(x_crops)
+            res = self.decode(cls_score, bbox_pred, cls_align, target_sz, p).cpu().numpy()     # the frame's one D2H read
+        _, _, pred_x1, pred_y1, pred_x2, pred_y2, penalty, score = res
+        score = np.float32(score)
+        pred_xs, pred_ys = (pred_x1 + pred_x2) / 2, (pred_y1 + pred_y2) / 2
+        pred_w, pred_h = pred_x2 - pred_x1, pred_y2 - pred_y1
+        diff_xs, diff_ys = pred_xs - p.instance_size // 2, pred_ys - p.instance_size // 2
+        diff_xs, diff_ys, pred_w, pred_h = diff_xs / scale_z, diff_ys / scale_z, pred_w / scale_z, pred_h / scale_z
+        target_sz = target_sz / scale_z
+        lr = penalty * score * p.lr
+        res_xs, res_ys = target_pos[0] + diff_xs, target_pos[1] + diff_ys
+        res_w = pred_w * lr + (1 - lr) * target_sz[0]
+        res_h = pred_h * lr + (1 - lr) * target_sz[1]
+        target_pos = np.array([res_xs, res_ys])
+        target_sz = target_sz * (1 - lr) + lr * np.array([res_w, res_h])
+        return target_pos, target_sz, score
+
+    def track(self, image, info: dict = None) -> dict:
+        state = self.state
+        p, net, avg_chans, window = state["p"], state["net"], state["avg_chans"], state["window"]
+        target_pos, target_sz = state["target_pos"], state["target_sz"]
+        hc_z = target_sz[1] + p.context_amount * sum(target_sz)
+        wc_z = target_sz[0] + p.context_amount * sum(target_sz)
+        s_z = np.sqrt(wc_z * hc_z)
+        scale_z = p.exemplar_size / s_z
+        d_search = (p.instance_size - p.exemplar_size) / 2
+        pad = d_search / scale_z
+        s_x = s_z + 2 * pad
+        x_crop = self.get_subwindow_tracking(image, target_pos, p.instance_size, self.python2round(s_x), avg_chans)
+        target_pos, target_sz, cls_score = self.update(net, self._normalize(x_crop), target_pos, target_sz * scale_z,
+                                                       window, scale_z, p)
+        target_pos[0] = max(0, min(state["im_w"], target_pos[0]))
+        target_pos[1] = max(0, min(state["im_h"], target_pos[1]))
+        target_sz[0] = max(10, min(state["im_w"], target_sz[0]))
+        target_sz[1] = max(10, min(state["im_h"], target_sz[1]))
+        state["target_pos"], state["target_sz"] = target_pos, target_sz
+        self.state = state
+        return {"target_bbox": [target_pos[0] - target_sz[0] / 2, target_pos[1] - target_sz[1] / 2, target_sz[0], target_sz[1]],
+                "best_score": cls_score}

@@ -706,6 +706,35 @@ def case_ocean_model(seed=29):
     save("g19_ocean_model", seed=seed, **out)
 
 
+def case_ocean_tracker(seed=37):
+    """G20: Ocean_Tracker.update (score mixing, penalties, window, arg-max, box update) on seeded network outputs, and
+    its crop window without resize."""
+    from pysot_toolkit.trackers.ocean_tracker import Ocean_Tracker, OceanConfig
+    p = OceanConfig()
+    S = p.score_size
+    trk = Ocean_Tracker("t", None)
+    trk.grids(p)
+    window = np.outer(np.hanning(S), np.hanning(S))
+    out = {"score_size": S}
+    for i in range(4):
+        maps = (torch.from_numpy(det_input("cls%d" % i, (1, 1, S, S), seed, -4, 4)),
+                torch.from_numpy(det_input("ltrb%d" % i, (1, 4, S, S), seed, 5, 90)),
+                torch.from_numpy(det_input("al%d" % i, (1, 1, S, S), seed, -4, 4)))
+        net = types.SimpleNamespace(track=lambda x, m=maps: m)
+        tpos, tsz, scale_z = np.array([100.0 + 7 * i, 80.0 - 3 * i]), np.array([40.0 + 5 * i, 60.0 - 4 * i]), 0.8 + 0.15 * i
+        pos, sz, sc = trk.update(net, None, tpos, tsz * scale_z, window, scale_z, p)
+        out["pos%d" % i], out["sz%d" % i], out["score%d" % i] = pos, sz, np.float32(sc)
+    im = det_input("frame", (120, 160, 3), seed, 0, 256, np.uint8)
+    avg = np.mean(im, axis=(0, 1))
+    for i, (pos, sz) in enumerate([((80.0, 60.0), 64), ((4.5, 6.5), 47), ((157.5, 117.5), 52), ((30.5, 100.5), 127)]):
+        out["sub%d" % i] = trk.get_subwindow_tracking(im, np.array(pos), sz, sz, avg).numpy().astype(np.uint8)
+    out["sub_pos"] = np.array([[80.0, 60.0], [4.5, 6.5], [157.5, 117.5], [30.5, 100.5]])
+    out["sub_sz"] = np.array([64, 47, 52, 127])
+    out["avg"] = avg
+    out["p2round"] = np.array([trk.python2round(v) for v in (0.5, 1.5, 2.5, 2.4, 254.5, 255.5, 100.49)])
+    save("g20_ocean_tracker", seed=seed, **out)
+
+
 def case_ocean(seed=23):
     """G17: the Siamese head around the correlation: neck, box_tower (encoders, correlation, towers, heads) forward
     and gradients in train mode, forward in eval mode, pred_to_image / offsets, label generator, criterion."""
@@ -865,7 +894,7 @@ CASES = {
     "decode": case_decode, "compaction": case_compaction, "boxes": case_boxes,
     "matcher_criterion": case_matcher_criterion, "tracker_post": case_tracker_post,
     "xcorr": case_xcorr, "ema": case_ema, "pre_pos": case_preprocess_posenc,
-    "student": case_student, "transforms": case_transforms, "ocean": case_ocean, "ocean_model": case_ocean_model, "crop": case_crop,
+    "student": case_student, "transforms": case_transforms, "ocean": case_ocean, "ocean_tracker": case_ocean_tracker, "ocean_model": case_ocean_model, "crop": case_crop,
 }
 
 

@@ -152,3 +152,40 @@ def test_ocean_model_end_to_end():
     actor(mode="update", keep_rate=0.5)
     want = 0.5 * next(student.parameters()) + 0.5 * before
     _close(next(teacher.parameters()), want.detach().cpu().numpy(), 1e-6, "ema")
+
+
+def test_ocean_tracker_update_and_crop_golden():
+    """Ocean_Tracker: the decode kernel + host update against the reference's update() (g20); crop windows against
+    its get_subwindow_tracking; python2round; then a short sequence through the real network runs and stays finite."""
+    import os
+    from spot_amd.ocean_model import ocean_resnet50
+    from spot_amd.ocean_tracker import Ocean_Tracker, OceanConfig
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g20_ocean_tracker.npz"))
+    S, seed = int(g["score_size"]), int(g["seed"])
+    p = OceanConfig()
+    assert p.score_size == S
+    trk = Ocean_Tracker("t", None)
+    window = np.outer(np.hanning(S), np.hanning(S))
+    trk._window_dev = torch.from_numpy(window).to(DEV)
+    for i in range(4):
+        maps = (G(det_input("cls%d" % i, (1, 1, S, S), seed, -4, 4)), G(det_input("ltrb%d" % i, (1, 4, S, S), seed, 5, 90)),
+                G(det_input("al%d" % i, (1, 1, S, S), seed, -4, 4)))
+        net = types.SimpleNamespace(track=lambda x, m=maps: m)
+        tpos, tsz, scale_z = np.array([100.0 + 7 * i, 80.0 - 3 * i]), np.array([40.0 + 5 * i, 60.0 - 4 * i]), 0.8 + 0.15 * i
+        pos, sz, sc = trk.update(net, None, tpos, tsz * scale_z, window, scale_z, p)
+        np.testing.assert_allclose(pos, g["pos%d" % i], rtol=1e-6)
+        np.testing.assert_allclose(sz, g["sz%d" % i], rtol=1e-6)
+        np.testing.assert_allclose(sc, g["score%d" % i], rtol=2e-6)
+    im = det_input("frame", (120, 160, 3), seed, 0, 256, np.uint8)
+    for i, (pos, sz) in enumerate(zip(g["sub_pos"], g["sub_sz"])):
+        got = trk.get_subwindow_tracking(im, np.array(pos), int(sz), int(sz), g["avg"])
+        assert np.array_equal(got[0].cpu().numpy(), g["sub%d" % i]), i
+    assert [trk.python2round(v) for v in (0.5, 1.5, 2.5, 2.4, 254.5, 255.5, 100.49)] == list(g["p2round"])
+    net = det_fill_positive_norm_(ocean_resnet50(_settings(device="cpu"), "teacher"), 9).to(DEV).eval()
+    trk = Ocean_Tracker("t", net)
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 255, size=(4, 240, 320, 3), dtype=np.uint8)
+    trk.initialize(frames[0], {"init_bbox": [120.0, 90.0, 60.0, 50.0]})
+    for f in frames[1:]:
+        out = trk.track(f)
+        assert np.isfinite(out["target_bbox"]).all() and out["target_bbox"][2] >= 10 and 0 <= out["best_score"] <= 1

@@ -390,3 +390,35 @@ def test_g19_ocean_actor_decode(golden):
     np.testing.assert_allclose(score.numpy(), g["best_score"], rtol=1e-6)
     np.testing.assert_allclose(conf.numpy(), g["best_conf"], rtol=0, atol=0)
     assert (g["best_bbox"][0, 2:] == 1.0).all()
+
+
+def _ocean_tracker_case(g, i):
+    S, seed = int(g["score_size"]), int(g["seed"])
+    maps = (det_input("cls%d" % i, (1, 1, S, S), seed, -4, 4), det_input("ltrb%d" % i, (1, 4, S, S), seed, 5, 90),
+            det_input("al%d" % i, (1, 1, S, S), seed, -4, 4))
+    return maps, np.array([100.0 + 7 * i, 80.0 - 3 * i]), np.array([40.0 + 5 * i, 60.0 - 4 * i]), 0.8 + 0.15 * i
+
+
+def test_g20_ocean_tracker_update(golden):
+    """Ocean_Tracker.update restated == the reference's, and its crop windows (origin by Python's round)."""
+    g = golden("g20_ocean_tracker")
+    S = int(g["score_size"])
+    window = np.outer(np.hanning(S), np.hanning(S))
+    for i in range(4):
+        (cls, ltrb, al), tpos, tsz, scale_z = _ocean_tracker_case(g, i)
+        pos, sz, sc = O.ocean_tracker_update(cls[0, 0], ltrb[0], al[0, 0], tpos, tsz * scale_z, window, scale_z)
+        np.testing.assert_allclose(pos, g["pos%d" % i], rtol=1e-6)
+        np.testing.assert_allclose(sz, g["sz%d" % i], rtol=1e-6)
+        np.testing.assert_allclose(sc, g["score%d" % i], rtol=1e-6)
+    im = det_input("frame", (120, 160, 3), int(g["seed"]), 0, 256, np.uint8)
+    for i, (pos, sz) in enumerate(zip(g["sub_pos"], g["sub_sz"])):
+        sz = int(sz)
+        c = (sz + 1) / 2
+        x0, y0 = round(pos[0] - c), round(pos[1] - c)
+        # the same window through crop_window: its origin floor(p - c + 0.5) differs from round() on exact halves only
+        pad = np.zeros((sz, sz, 3), np.uint8)
+        pad[:] = g["avg"].astype(np.uint8)
+        ys, xs = np.arange(y0, y0 + sz), np.arange(x0, x0 + sz)
+        iy, ix = (ys >= 0) & (ys < 120), (xs >= 0) & (xs < 160)
+        pad[np.ix_(iy, ix)] = im[np.ix_(ys[iy], xs[ix])]
+        assert np.array_equal(pad.transpose(2, 0, 1), g["sub%d" % i]), i
