@@ -56,7 +56,78 @@ def timed(fn, steps, warmup=2):
     return e0.elapsed_time(e1) / steps
 
 
+def variant(steps):
+    """The assembled SP-Ocean variant with the reference's settings (spot_ocean_003.py: 4-layer towers, 255 / 127 crops):
+    online tracker rate, and one sparse-supervised iteration (teacher pseudo-labelling of 24 clips, student step on
+    8 + 24 pairs with in-network augmentation, backward)."""
+    import time
+    import types
+    import numpy as np
+    from spot_amd.ocean_model import OceanSparseActor, ocean_resnet50
+    from spot_amd.ocean_tracker import Ocean_Tracker
+    from spot_amd.tensordict import TensorDict
+    S = types.SimpleNamespace(
+        device="cuda", used_layers=[3], before_neck_dim=1024, head_dim=256, head_tower_num=4, iou_prediction_tag=True,
+        strong_augmentation_tag=True, aug_settings={"gray": 0.05, "jitter": 0.2, "angle": 10, "lr_f_prob": 0.35, "ud_f_prob": 0.1},
+        normalize_mean=[0.485, 0.456, 0.406], normalize_std=[0.229, 0.224, 0.225], search_sz=255, temp_sz=127, output_sz=25,
+        batch_size=32, stride=8, search_feature_sz=25,
+        curriculum_settings={"confidence_threshold": 0.82, "window_penalty": 0.30, "cls_ratio": 0.94},
+        weight_dict={"loss_ce_sup": 1, "loss_bbox_sup": 1, "loss_align_sup": 1, "loss_iou_pred_sup": 0.5,
+                     "loss_ce_unsup": 1, "loss_bbox_unsup": 1, "loss_align_unsup": 1})
+    cpu = types.SimpleNamespace(**{**vars(S), "device": "cpu"})
+    student = det_fill_positive_norm_(ocean_resnet50(cpu, "student"), 1).cuda()
+    teacher = det_fill_positive_norm_(ocean_resnet50(cpu, "teacher"), 2).cuda()
+    rng = np.random.default_rng(0)
+    # ---- tracker
+    trk = Ocean_Tracker("t", teacher.eval())
+    frames = rng.integers(0, 255, size=(50, 256, 256, 3), dtype=np.uint8)
+    for rep in range(2):
+        trk.initialize(frames[0], {"init_bbox": [96.0, 96.0, 64.0, 64.0]})
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in frames[1:]:
+            trk.track(f)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    print(json.dumps({"config": "SP-Ocean tracker API, B=1, 49 track() calls on 256x256 frames (frame upload, device crop, "
+                                "network, decode kernel, one D2H), eager launches", "value": round(49 / el, 2),
+                      "unit": "frames/s", "ms_per_frame": round(el / 49 * 1e3, 3)}))
+    # ---- one sparse-supervised iteration
+    teacher.train(), student.train()
+    actor = OceanSparseActor(S, student, teacher, ocean.ocean_loss(S))
+
+    def pair(t, s, n):
+        d = TensorDict()
+        d[t + "_images"] = torch.from_numpy(rng.integers(0, 255, (n, 3, 127, 127), dtype=np.uint8)).cuda()
+        d[s + "_images"] = torch.from_numpy(rng.integers(0, 255, (n, 3, 255, 255), dtype=np.uint8)).cuda()
+        d[t + "_avg"], d[s + "_avg"] = torch.rand(n, 3).cuda() * 255, torch.rand(n, 3).cuda() * 255
+        d[t + "_anno"] = torch.tensor([[40.0, 40.0, 50.0, 45.0]]).repeat(n, 1).cuda()
+        d[s + "_anno"] = torch.cat([torch.rand(n, 2) * 60 + 60, torch.rand(n, 2) * 50 + 40], 1).cuda()
+        return d
+    teach, sup, sp = pair("key", "unlabeled", 24), pair("template", "search", 8), pair("relay", "aug", 24)
+    sup["masks"] = torch.zeros(8, dtype=torch.bool, device="cuda")
+    sp["masks"] = torch.ones(24, dtype=torch.bool, device="cuda")
+    params = list(student.parameters())
+
+    def iteration():
+        pseudo = actor(mode="inference", teacher_data=TensorDict(dict(teach)))
+        spd = TensorDict(dict(sp))
+        spd["aug_anno"] = pseudo["best_bbox"]
+        for p_ in params:
+            p_.grad = None
+        loss, _ = actor(mode="spsup", burnin_data=TensorDict(dict(sup)), sp_data=spd)
+        loss.backward()
+    ms = timed(iteration, steps)
+    print(json.dumps({"config": "SP-Ocean iteration: teacher pseudo-labels on 24 clips (train-mode teacher), student "
+                                "step on 8 + 24 pairs with in-network augmentation, forward + backward, fp32, eager",
+                      "ms_per_iteration": ms, "value": round(32 / ms * 1e3, 1), "unit": "clips/s",
+                      "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "variant":
+        lib.load()
+        return variant(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--search", type=int, default=384, choices=(255, 384))
