@@ -372,11 +372,12 @@ int spot_ocean_labels_f32(const float* anno_xywh, float* cls, double* reg, float
 
 /* One frame of the Siamese online tracker (pysot_toolkit/trackers/ocean_tracker.py:71-104): from the classification
  * and align logits [S,S], the ltrb map [4,S,S], the float64 cosine window [S,S] and the target size scaled to the
- * crop, the winning cell after score mixing (ratio), scale / aspect penalty (penalty_k) and window blend
+ * crop (target_wh: two float64 values in device memory, so that a captured launch can be replayed with a new size),
+ * the winning cell after score mixing (ratio), scale / aspect penalty (penalty_k) and window blend
  * (window_influence).  out8 (device, float64) = (row, col, x1, y1, x2, y2, penalty, mixed score) of that cell. */
 int spot_ocean_tracker_decode(const float* cls_logits, const float* align_logits, const float* ltrb, const double* window,
-                              double target_w, double target_h, double ratio, double penalty_k, double window_influence,
-                              int S, int stride, int instance_size, double* out8, hipStream_t stream);
+                              const double* target_wh, double ratio, double penalty_k, double window_influence, int S,
+                              int stride, int instance_size, double* out8, hipStream_t stream);
 
 /* ---- BatchNorm2d fused with the ReLU / residual add that follow it in the ResNet bottleneck
  * (ltr/models/backbone/resnet.py:72-92,196-198; the Siamese head's conv-bn-relu stacks,

@@ -52,12 +52,14 @@ __global__ __launch_bounds__(256) void ocean_labels_kernel(const float* __restri
 // (its grid is float64); the first maximum wins.  out[8] = (row, col, x1, y1, x2, y2, penalty, score) of that cell.
 __global__ __launch_bounds__(256) void ocean_tracker_decode_kernel(const float* __restrict__ cls, const float* __restrict__ align,
                                                                    const float* __restrict__ ltrb, const double* __restrict__ window,
-                                                                   double tw, double th, float ratio, float one_minus_ratio,
+                                                                   const double* __restrict__ target_wh, float ratio,
+                                                                   float one_minus_ratio,
                                                                    double penalty_k, double window_influence, int S, int stride,
                                                                    int instance, double* __restrict__ out) {
     __shared__ double bv[256];
     __shared__ int bi[256];
     const int n = S * S;
+    const double tw = target_wh[0], th = target_wh[1];
     double best = -1.0 / 0.0;
     int besti = n;
     const double pad_t = (tw + th) * 0.5, sz_t = sqrt((tw + pad_t) * (th + pad_t));
@@ -113,12 +115,12 @@ __global__ __launch_bounds__(256) void ocean_tracker_decode_kernel(const float* 
 }  // namespace
 
 extern "C" int spot_ocean_tracker_decode(const float* cls_logits, const float* align_logits, const float* ltrb,
-                                         const double* window, double target_w, double target_h, double ratio,
+                                         const double* window, const double* target_wh, double ratio,
                                          double penalty_k, double window_influence, int S, int stride, int instance_size,
                                          double* out8, hipStream_t stream) {
-    SPOT_CHECK_ARG(cls_logits && align_logits && ltrb && window && out8, "ocean_tracker_decode: null pointer");
+    SPOT_CHECK_ARG(cls_logits && align_logits && ltrb && window && target_wh && out8, "ocean_tracker_decode: null pointer");
     SPOT_CHECK_ARG(S > 0 && stride > 0 && instance_size > 0, "ocean_tracker_decode: bad shape");
-    ocean_tracker_decode_kernel<<<1, 256, 0, stream>>>(cls_logits, align_logits, ltrb, window, target_w, target_h, (float)ratio,
+    ocean_tracker_decode_kernel<<<1, 256, 0, stream>>>(cls_logits, align_logits, ltrb, window, target_wh, (float)ratio,
                                                        (float)(1.0 - ratio), penalty_k, window_influence, S, stride,
                                                        instance_size, out8);
     SPOT_CHECK_LAUNCH("ocean_tracker_decode");

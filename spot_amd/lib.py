@@ -81,7 +81,7 @@ SIGNATURES = {
     "spot_ellipse_rotate_boxes_f32": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "spot_channel_scale_f32": [vp, vp, i64, i32, vp],
     "spot_ocean_labels_f32": [vp] * 5 + [i32] * 4 + [f32, i32, vp],
-    "spot_ocean_tracker_decode": [vp] * 4 + [f64] * 5 + [i32] * 3 + [vp, vp],
+    "spot_ocean_tracker_decode": [vp] * 5 + [f64] * 3 + [i32] * 3 + [vp, vp],
     "spot_crop_resize_u8": [vp, vp, i32, vp],
     "spot_crop_resize_batch_u8": [vp, i32, vp, i32, vp],
     "spot_deform_im2col_f32": [vp] * 3 + [i32] * 12 + [vp],

@@ -2,7 +2,9 @@
 frame is cut, padded and resized on the device, normalised by the preprocess kernel, run through Ocean.track, and
 reduced to the winning cell by one kernel; eight float64 values come back to the host per frame, where the
 reference's scalar box update follows."""
+import os
 import time
+import warnings
 
 import numpy as np
 import torch
@@ -25,11 +27,20 @@ class OceanConfig(object):
 
 
 class Ocean_Tracker(object):
-    def __init__(self, name, net):
+    def __init__(self, name, net, use_graph=None):
+        """use_graph: replay a frame's device work (normalise, network, decode) as one captured HIP graph from the
+        third frame of a sequence on.  Default: on for this package's Ocean model (whose track() is a pure device
+        function of the crop and the cached template features) unless SPOT_TRACKER_GRAPH=0; off for any other net."""
         self.name, self.net = name, net
         self.p = OceanConfig()
         self.state = None
         self.mean, self.std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+        if use_graph is None:
+            from .ocean_model import Ocean
+            use_graph = os.environ.get("SPOT_TRACKER_GRAPH", "1") == "1" and isinstance(net, Ocean)
+        self.use_graph = bool(use_graph)
+        self._graph, self._eager_frames = None, 0
+        self._target_dev = None
 
     def initialize_features(self):
         if not getattr(self, "features_initialized", False) and hasattr(self.net, "initialize"):
@@ -84,25 +95,62 @@ class Ocean_Tracker(object):
         else:
             window = np.ones((int(p.score_size), int(p.score_size)))
         self._window_dev = torch.from_numpy(np.ascontiguousarray(window)).cuda()
+        self._graph, self._eager_frames = None, 0        # a captured graph reads the previous template's features
         state.update(p=p, net=self.net, avg_chans=avg_chans, window=window, target_pos=target_pos, target_sz=target_sz)
         self.state = state
         return {"time": time.time() - tic}
 
-    def decode(self, cls_score, bbox_pred, cls_align, target_sz, p):
-        """Device part of update(): the winning cell as eight float64 values (see spot_ocean_tracker_decode)."""
+    def decode(self, cls_score, bbox_pred, cls_align, p):
+        """Device part of update(): the winning cell as eight float64 values (see spot_ocean_tracker_decode); the
+        target size is read from self._target_dev."""
         S = int(p.score_size)
         out = torch.empty((8,), dtype=torch.float64, device=cls_score.device)
         lib.call("spot_ocean_tracker_decode", ops._p(cls_score.contiguous()), ops._p(cls_align.contiguous()),
-                 ops._p(bbox_pred.contiguous()), ops._p(self._window_dev), float(target_sz[0]), float(target_sz[1]),
-                 float(p.ratio), float(p.penalty_k), float(p.window_influence), S, int(p.total_stride),
-                 int(p.instance_size), ops._p(out), ops._st())
+                 ops._p(bbox_pred.contiguous()), ops._p(self._window_dev), ops._p(self._target_dev), float(p.ratio),
+                 float(p.penalty_k), float(p.window_influence), S, int(p.total_stride), int(p.instance_size), ops._p(out),
+                 ops._st())
         return out
+
+    def _device_pipeline(self, net, x_crops, p):
+        cls_score, bbox_pred, cls_align = net.track(x_crops)
+        return self.decode(cls_score, bbox_pred, cls_align, p)
+
+    def _run_frame(self, net, x_crops, p):
+        if not self.use_graph or x_crops is None:
+            return self._device_pipeline(net, x_crops, p)
+        if self._graph is None:
+            if self._eager_frames < 2:
+                self._eager_frames += 1
+                return self._device_pipeline(net, x_crops, p)
+            try:
+                self._x_static = x_crops.clone()
+                cap = torch.cuda.Stream()
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cap):             # per-stream handles and code objects exist before capture
+                    self._device_pipeline(net, self._x_static, p)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=cap):
+                    self._out_static = self._device_pipeline(net, self._x_static, p)
+                self._graph = graph
+            except Exception as e:                       # capture unsupported: stay eager, say so once
+                warnings.warn("spot_amd Ocean tracker: HIP graph capture failed (%s); running eagerly" % (e,))
+                torch.cuda.synchronize()
+                self.use_graph = False
+                return self._device_pipeline(net, x_crops, p)
+        self._x_static.copy_(x_crops)
+        self._graph.replay()
+        return self._out_static
 
     def update(self, net, x_crops, target_pos, target_sz, window, scale_z, p):
         """ocean_tracker.py:71-130."""
         with torch.no_grad():
-            cls_score, bbox_pred, cls_align = net.track(x_crops)
-            res = self.decode(cls_score, bbox_pred, cls_align, target_sz, p).cpu().numpy()     # the frame's one D2H read
+            tgt = torch.tensor([float(target_sz[0]), float(target_sz[1])], dtype=torch.float64)
+            if self._target_dev is None:
+                self._target_dev = tgt.cuda()
+            else:
+                self._target_dev.copy_(tgt)
+            res = self._run_frame(net, x_crops, p).cpu().numpy()                               # the frame's one D2H read
         _, _, pred_x1, pred_y1, pred_x2, pred_y2, penalty, score = res
         score = np.float32(score)
         pred_xs, pred_ys = (pred_x1 + pred_x2) / 2, (pred_y1 + pred_y2) / 2

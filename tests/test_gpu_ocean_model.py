@@ -182,10 +182,15 @@ def test_ocean_tracker_update_and_crop_golden():
         assert np.array_equal(got[0].cpu().numpy(), g["sub%d" % i]), i
     assert [trk.python2round(v) for v in (0.5, 1.5, 2.5, 2.4, 254.5, 255.5, 100.49)] == list(g["p2round"])
     net = det_fill_positive_norm_(ocean_resnet50(_settings(device="cpu"), "teacher"), 9).to(DEV).eval()
-    trk = Ocean_Tracker("t", net)
     rng = np.random.default_rng(0)
-    frames = rng.integers(0, 255, size=(4, 240, 320, 3), dtype=np.uint8)
-    trk.initialize(frames[0], {"init_bbox": [120.0, 90.0, 60.0, 50.0]})
-    for f in frames[1:]:
-        out = trk.track(f)
-        assert np.isfinite(out["target_bbox"]).all() and out["target_bbox"][2] >= 10 and 0 <= out["best_score"] <= 1
+    frames = rng.integers(0, 255, size=(8, 240, 320, 3), dtype=np.uint8)
+    runs = []
+    for graph in (False, True):                      # eager launches, then the captured graph from the third frame on
+        trk = Ocean_Tracker("t", net, use_graph=graph)
+        trk.initialize(frames[0], {"init_bbox": [120.0, 90.0, 60.0, 50.0]})
+        outs = [trk.track(f) for f in frames[1:]]
+        assert (trk._graph is not None) == graph
+        for out in outs:
+            assert np.isfinite(out["target_bbox"]).all() and out["target_bbox"][2] >= 10 and 0 <= out["best_score"] <= 1
+        runs.append(np.array([o["target_bbox"] + [float(o["best_score"])] for o in outs]))
+    np.testing.assert_array_equal(runs[0], runs[1])

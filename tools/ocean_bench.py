@@ -90,8 +90,8 @@ def variant(steps):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
     print(json.dumps({"config": "SP-Ocean tracker API, B=1, 49 track() calls on 256x256 frames (frame upload, device crop, "
-                                "network, decode kernel, one D2H), eager launches", "value": round(49 / el, 2),
-                      "unit": "frames/s", "ms_per_frame": round(el / 49 * 1e3, 3)}))
+                                "network, decode kernel, one D2H)", "value": round(49 / el, 2),
+                      "unit": "frames/s", "ms_per_frame": round(el / 49 * 1e3, 3), "graph_replay": trk._graph is not None}))
     # ---- one sparse-supervised iteration
     teacher.train(), student.train()
     actor = OceanSparseActor(S, student, teacher, ocean.ocean_loss(S))
