@@ -283,6 +283,147 @@ __global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __rest
     }
 }
 
+// ---- the same three transforms for any map size and padding (undilated): tiles cover the Ho x Wo output grid,
+// TH x TW of them per clip, partial ones masked; the input patch of tile (ty, tx) starts at (4 ty - pad, 4 tx - pad).
+// Used for the Siamese head's 25x25 ... 45x45 maps with padding 0 or 1 (ltr/models/neck/ocean_fusion.py:56-85,
+// 126-135) and for the input gradient of such a convolution (padding 2 - pad on the output gradient).  The tile
+// count is rounded up to a multiple of 32 (Pp) with zero columns so the products keep whole aligned tiles.
+struct GenGeo {
+    int Hin, Win, Ho, Wo, pad, TH, TW;
+};
+
+__global__ __launch_bounds__(256) void wino_input_gen_kernel(const float* __restrict__ x, float* __restrict__ V, int C,
+                                                             GenGeo g, int P, int Pp) {
+    const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (p >= Pp) return;
+    const size_t plane = (size_t)C * Pp;
+    float* vp = V + (size_t)c * Pp + p;
+    if (p >= P) {
+#pragma unroll
+        for (int k = 0; k < XI; ++k) vp[(size_t)k * plane] = 0.f;
+        return;
+    }
+    const int T = g.TH * g.TW, b = p / T, t = p - b * T, ty = t / g.TW, tx = t - ty * g.TW;
+    const float* base = x + ((size_t)b * C + c) * g.Hin * g.Win;
+    const int r0 = 4 * ty - g.pad, c0 = 4 * tx - g.pad;
+    float d[6][6], tmp[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int r = r0 + i;
+        const bool rin = r >= 0 && r < g.Hin;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int cc = c0 + j;
+            d[i][j] = (rin && cc >= 0 && cc < g.Win) ? base[(size_t)r * g.Win + cc] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float o[6];
+        bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][j] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float o[6];
+        bt6(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], tmp[i][4], tmp[i][5], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) vp[(size_t)(i * 6 + j) * plane] = o[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void wino_output_gen_kernel(const float* __restrict__ Mb, float* __restrict__ y,
+                                                              const float* __restrict__ bias, int C, GenGeo g, int P, int Pp) {
+    const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (p >= P) return;
+    const int T = g.TH * g.TW, b = p / T, t = p - b * T, ty = t / g.TW, tx = t - ty * g.TW;
+    const size_t plane = (size_t)C * Pp;
+    const float* mp = Mb + (size_t)c * Pp + p;
+    const float add = bias ? bias[c] : 0.f;
+    float tmp[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float o[4];
+        at6(mp[(size_t)j * plane], mp[(size_t)(6 + j) * plane], mp[(size_t)(12 + j) * plane], mp[(size_t)(18 + j) * plane],
+            mp[(size_t)(24 + j) * plane], mp[(size_t)(30 + j) * plane], o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tmp[i][j] = o[i];
+    }
+    float* yp = y + ((size_t)b * C + c) * g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * ty + i;
+        if (r >= g.Ho) break;
+        float o[4];
+        at6(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], tmp[i][4], tmp[i][5], o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cc = 4 * tx + j;
+            if (cc < g.Wo) yp[(size_t)r * g.Wo + cc] = o[j] + add;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino_outgrad_gen_kernel(const float* __restrict__ dy, float* __restrict__ dM, int C,
+                                                               GenGeo g, int P, int Pp) {
+    const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (p >= Pp) return;
+    const size_t plane = (size_t)C * Pp;
+    float* mp = dM + (size_t)c * Pp + p;
+    if (p >= P) {
+#pragma unroll
+        for (int k = 0; k < XI; ++k) mp[(size_t)k * plane] = 0.f;
+        return;
+    }
+    const int T = g.TH * g.TW, b = p / T, t = p - b * T, ty = t / g.TW, tx = t - ty * g.TW;
+    const float* yp = dy + ((size_t)b * C + c) * g.Ho * g.Wo;
+    float r[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rr = 4 * ty + i, cc = 4 * tx + j;
+            r[i][j] = (rr < g.Ho && cc < g.Wo) ? yp[(size_t)rr * g.Wo + cc] : 0.f;
+        }
+    float tmp[6][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float o[6];
+        a4(r[0][j], r[1][j], r[2][j], r[3][j], o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][j] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float o[6];
+        a4(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) mp[(size_t)(i * 6 + j) * plane] = o[j];
+    }
+}
+
+struct GenPlan {
+    GenGeo g;
+    int P, Pp;
+    long U, V, M;
+    bool ok;
+};
+GenPlan gen_plan(int B, int Cin, int Cout, int Hin, int Win, int pad) {
+    GenPlan q = {};
+    q.g.Hin = Hin; q.g.Win = Win; q.g.pad = pad;
+    q.g.Ho = Hin + 2 * pad - 2; q.g.Wo = Win + 2 * pad - 2;
+    q.ok = B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0 && pad >= 0 && pad <= 2 && q.g.Ho > 0 && q.g.Wo > 0 &&
+           Cin <= 65535 && Cout <= 65535;
+    if (!q.ok) return q;
+    q.g.TH = (q.g.Ho + 3) / 4; q.g.TW = (q.g.Wo + 3) / 4;
+    const long P = (long)B * q.g.TH * q.g.TW, Pp = (P + 31) / 32 * 32;
+    q.ok = Pp < (1L << 31) && Pp * (long)(Cin > Cout ? Cin : Cout) * XI < (1L << 40);
+    q.P = (int)P; q.Pp = (int)Pp;
+    q.U = (long)XI * Cout * Cin; q.V = (long)XI * Cin * Pp; q.M = (long)XI * Cout * Pp;
+    return q;
+}
+
 struct Sizes {
     long U, V, M;
 };
@@ -398,5 +539,82 @@ extern "C" int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* v_ke
     if (rc != SPOT_OK) return rc;
     wino_wgrad_out_kernel<<<spot_ceil_div((long)Cout * Cin, 256), 256, 0, stream>>>(dU, dw, Cout, Cin, accumulate);
     SPOT_CHECK_LAUNCH("conv3x3_winograd_wgrad(weights)");
+    return SPOT_OK;
+}
+
+
+// ---- any map size, padding 0 / 1 / 2, undilated (see GenGeo) -----------------------------------------------------
+extern "C" long spot_conv3x3_winograd_general_ws_floats(int B, int Cin, int Cout, int Hin, int Win, int pad) {
+    const GenPlan q = gen_plan(B, Cin, Cout, Hin, Win, pad);
+    return q.ok ? q.U + q.V + q.M : 0;
+}
+
+extern "C" long spot_conv3x3_winograd_general_v_floats(int B, int Cin, int Hin, int Win, int pad) {
+    const GenPlan q = gen_plan(B, Cin, 1, Hin, Win, pad);
+    return q.ok ? q.V : 0;
+}
+
+extern "C" int spot_conv3x3_winograd_general_f32(const float* in, const float* w, const float* bias, float* out, float* ws,
+                                                 float* v_keep, int B, int Cin, int Cout, int Hin, int Win, int pad,
+                                                 int flip, hipStream_t stream) {
+    SPOT_CHECK_ARG(in && w && out && ws, "conv3x3_winograd_general: null pointer");
+    const GenPlan q = gen_plan(B, Cin, Cout, Hin, Win, pad);
+    SPOT_CHECK_ARG(q.ok, "conv3x3_winograd_general: bad shape B=%d Cin=%d Cout=%d H=%d W=%d pad=%d", B, Cin, Cout, Hin, Win, pad);
+    SPOT_CHECK_ARG((((uintptr_t)ws | (uintptr_t)v_keep) & 15) == 0, "conv3x3_winograd_general: ws / v_keep must be 16-byte aligned");
+    float* U = ws;
+    float* V = v_keep ? v_keep : ws + q.U;
+    float* Mb = ws + q.U + q.V;
+    wino_weights_kernel<<<spot_ceil_div((long)Cout * Cin, 256), 256, 0, stream>>>(w, U, Cout, Cin, flip);
+    SPOT_CHECK_LAUNCH("conv3x3_winograd_general(weights)");
+    wino_input_gen_kernel<<<dim3(spot_ceil_div(q.Pp, 256), Cin), 256, 0, stream>>>(in, V, Cin, q.g, q.P, q.Pp);
+    SPOT_CHECK_LAUNCH("conv3x3_winograd_general(input)");
+    spot_gemm_desc d = {};
+    d.A = U; d.B = V; d.C = Mb;
+    d.M = Cout; d.N = q.Pp; d.K = Cin; d.batch = XI;
+    d.transA = 0; d.transB = 1;
+    d.lda = Cin; d.ldb = q.Pp; d.ldc = q.Pp;
+    d.strideA = (long)Cout * Cin; d.strideB = (long)Cin * q.Pp; d.strideC = (long)Cout * q.Pp;
+    d.splitk = 1; d.alpha = 1.f;
+    const int rc = spot_gemm_f32(&d, stream);
+    if (rc != SPOT_OK) return rc;
+    wino_output_gen_kernel<<<dim3(spot_ceil_div(q.P, 256), Cout), 256, 0, stream>>>(Mb, out, bias, Cout, q.g, q.P, q.Pp);
+    SPOT_CHECK_LAUNCH("conv3x3_winograd_general(output)");
+    return SPOT_OK;
+}
+
+extern "C" int spot_conv3x3_winograd_general_wgrad_f32(const float* x, const float* v_kept, const float* dy, float* dw,
+                                                       float* ws, int B, int Cin, int Cout, int Hin, int Win, int pad,
+                                                       int accumulate, hipStream_t stream) {
+    SPOT_CHECK_ARG((x || v_kept) && dy && dw && ws, "conv3x3_winograd_general_wgrad: null pointer");
+    const GenPlan q = gen_plan(B, Cin, Cout, Hin, Win, pad);
+    SPOT_CHECK_ARG(q.ok, "conv3x3_winograd_general_wgrad: bad shape");
+    SPOT_CHECK_ARG((((uintptr_t)ws | (uintptr_t)v_kept) & 15) == 0, "conv3x3_winograd_general_wgrad: ws / v_kept must be 16-byte aligned");
+    float* dU = ws;
+    float* Vown = dU + q.U;
+    float* dM = Vown + q.V;
+    const float* V = v_kept;
+    if (!V) {
+        wino_input_gen_kernel<<<dim3(spot_ceil_div(q.Pp, 256), Cin), 256, 0, stream>>>(x, Vown, Cin, q.g, q.P, q.Pp);
+        SPOT_CHECK_LAUNCH("conv3x3_winograd_general_wgrad(input)");
+        V = Vown;
+    }
+    wino_outgrad_gen_kernel<<<dim3(spot_ceil_div(q.Pp, 256), Cout), 256, 0, stream>>>(dy, dM, Cout, q.g, q.P, q.Pp);
+    SPOT_CHECK_LAUNCH("conv3x3_winograd_general_wgrad(output gradient)");
+    const long wgs = (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * XI;
+    int sk = (int)((1536 + wgs - 1) / wgs);
+    if (sk > q.Pp / 256) sk = q.Pp / 256;
+    if (sk < 1) sk = 1;
+    if (sk > 1) SPOT_CHECK_HIP(hipMemsetAsync(dU, 0, (size_t)q.U * sizeof(float), stream));
+    spot_gemm_desc d = {};
+    d.A = dM; d.B = V; d.C = dU;
+    d.M = Cout; d.N = Cin; d.K = q.Pp; d.batch = XI;
+    d.transA = 0; d.transB = 0;
+    d.lda = q.Pp; d.ldb = q.Pp; d.ldc = Cin;
+    d.strideA = (long)Cout * q.Pp; d.strideB = (long)Cin * q.Pp; d.strideC = (long)Cout * Cin;
+    d.splitk = sk; d.accumulate = sk > 1; d.alpha = 1.f;
+    const int rc = spot_gemm_f32(&d, stream);
+    if (rc != SPOT_OK) return rc;
+    wino_wgrad_out_kernel<<<spot_ceil_div((long)Cout * Cin, 256), 256, 0, stream>>>(dU, dw, Cout, Cin, accumulate);
+    SPOT_CHECK_LAUNCH("conv3x3_winograd_general_wgrad(weights)");
     return SPOT_OK;
 }

@@ -66,9 +66,13 @@ def test_ocean_backbone_golden():
     (p3 * G(det_input("up", tuple(p3.shape), seed, -1, 1))).sum().backward()
     _close(x.grad[:, :, ::2, ::2], g["d_crop"], 2e-2, "d crop")        # 16 blocks of batch-statistics BatchNorm
     params = dict(net.named_parameters())
+    # parameter gradients behind up to 16 blocks of batch-statistics BatchNorm on a batch of two: a ReLU that flips
+    # under fp32 rounding moves single elements, so the bar is on the relative L2 error of each tensor
     for key in (k for k in g.files if k.startswith("d.")):
         got = params[key[2:]].grad
-        _close(got.reshape(-1)[::max(1, got.numel() // 4096)], g[key], 1e-2, key)
+        got = got.reshape(-1)[::max(1, got.numel() // 4096)].cpu().double().numpy()
+        err = np.linalg.norm(got - g[key]) / np.linalg.norm(g[key])
+        assert err < 2e-2, (key, err)
     _close(net.features.layer3[0].bn2.running_mean, g["running_mean_l3"], 1e-4, "running mean")
 
 
