@@ -215,20 +215,21 @@ long spot_conv3x3_winograd_wgrad_ws_floats(int B, int Cin, int Cout, int H, int 
 int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* v_kept, const float* dy, float* dw, float* ws, int B,
                                     int Cin, int Cout, int H, int W, int dilation, int accumulate, hipStream_t stream);
 
-/* The same Winograd path for any map size and padding 0, 1 or 2 (undilated; the 3x3 convolutions of the Siamese head
- * and backbone on 15x15 ... 63x63 maps, ltr/models/neck/ocean_fusion.py:56-85,126-135, ltr/models/backbone/
- * ocean_backbone.py:50-51): in [B,Cin,Hin,Win] -> out [B,Cout,Hin+2pad-2,Win+2pad-2], bias [Cout] or NULL added on
- * the way out.  flip = 1 with pad' = 2 - pad on the output gradient gives the input gradient.  v_keep (or NULL):
+/* The same Winograd path for any map size, dilation 1 or 2 per axis and padding = pad * dilation with pad 0, 1 or 2
+ * (the 3x3 convolutions of the Siamese head and backbone on 15x15 ... 63x63 maps, some dilated along one axis only:
+ * ltr/models/neck/ocean_fusion.py:56-85,126-158, ltr/models/backbone/ocean_backbone.py:50-51): in [B,Cin,Hin,Win] ->
+ * out [B,Cout,Hin+(2pad-2)dil_h,Win+(2pad-2)dil_w], bias [Cout] or NULL added on the way out.  flip = 1 with
+ * pad' = 2 - pad on the output gradient gives the input gradient.  v_keep (or NULL):
  * spot_conv3x3_winograd_general_v_floats(...) floats receiving the transformed input for the weight gradient.
  * The weight gradient takes x (or the kept v) and dy [B,Cout,Ho,Wo]; accumulate = 1 adds into dw. */
-long spot_conv3x3_winograd_general_ws_floats(int B, int Cin, int Cout, int Hin, int Win, int pad);
-long spot_conv3x3_winograd_general_v_floats(int B, int Cin, int Hin, int Win, int pad);
+long spot_conv3x3_winograd_general_ws_floats(int B, int Cin, int Cout, int Hin, int Win, int pad, int dil_h, int dil_w);
+long spot_conv3x3_winograd_general_v_floats(int B, int Cin, int Hin, int Win, int pad, int dil_h, int dil_w);
 int spot_conv3x3_winograd_general_f32(const float* in, const float* w, const float* bias, float* out, float* ws,
-                                      float* v_keep, int B, int Cin, int Cout, int Hin, int Win, int pad, int flip,
-                                      hipStream_t stream);
+                                      float* v_keep, int B, int Cin, int Cout, int Hin, int Win, int pad, int dil_h,
+                                      int dil_w, int flip, hipStream_t stream);
 int spot_conv3x3_winograd_general_wgrad_f32(const float* x, const float* v_kept, const float* dy, float* dw, float* ws,
-                                            int B, int Cin, int Cout, int Hin, int Win, int pad, int accumulate,
-                                            hipStream_t stream);
+                                            int B, int Cin, int Cout, int Hin, int Win, int pad, int dil_h, int dil_w,
+                                            int accumulate, hipStream_t stream);
 
 /* Patch matrix of a convolution (the 7x7 / stride 2 stem and layer2's 3x3 / stride 2 of the ResNet,
  * ltr/models/backbone/resnet.py:61,79,195-196, and the 3x3 convolutions of the Siamese head on odd-sized maps,

@@ -288,8 +288,26 @@ __global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __rest
 // Used for the Siamese head's 25x25 ... 45x45 maps with padding 0 or 1 (ltr/models/neck/ocean_fusion.py:56-85,
 // 126-135) and for the input gradient of such a convolution (padding 2 - pad on the output gradient).  The tile
 // count is rounded up to a multiple of 32 (Pp) with zero columns so the products keep whole aligned tiles.
+// Dilation (dh, dw), each 1 or 2, splits the map into dh*dw polyphase sub-maps (rows = a mod dh, columns = b mod dw)
+// that are convolved independently without dilation; `pad` counts sub-map pixels (the convolution's padding divided
+// by its dilation).  Sub-maps of an odd-sized map differ by one row / column; all use the tile grid of the largest.
 struct GenGeo {
-    int Hin, Win, Ho, Wo, pad, TH, TW;
+    int Hin, Win, Ho, Wo, pad, TH, TW, dh, dw;
+};
+
+struct GenTile {           // tile p: its clip, the sub-map's origin and extent in input and output, its tile position
+    int b, ty, tx, hs_in, ws_in, hs_out, ws_out;
+    size_t in_off, out_off;
+    __device__ __forceinline__ GenTile(const GenGeo& g, int p) {
+        const int T = g.TH * g.TW, S = g.dh * g.dw;
+        b = p / (S * T);
+        const int rem = p - b * (S * T), ph = rem / T, t = rem - ph * T;
+        const int a = ph / g.dw, bb = ph - a * g.dw;
+        ty = t / g.TW; tx = t - ty * g.TW;
+        hs_in = (g.Hin - a + g.dh - 1) / g.dh; ws_in = (g.Win - bb + g.dw - 1) / g.dw;
+        hs_out = (g.Ho - a + g.dh - 1) / g.dh; ws_out = (g.Wo - bb + g.dw - 1) / g.dw;
+        in_off = (size_t)a * g.Win + bb; out_off = (size_t)a * g.Wo + bb;
+    }
 };
 
 __global__ __launch_bounds__(256) void wino_input_gen_kernel(const float* __restrict__ x, float* __restrict__ V, int C,
@@ -303,18 +321,19 @@ __global__ __launch_bounds__(256) void wino_input_gen_kernel(const float* __rest
         for (int k = 0; k < XI; ++k) vp[(size_t)k * plane] = 0.f;
         return;
     }
-    const int T = g.TH * g.TW, b = p / T, t = p - b * T, ty = t / g.TW, tx = t - ty * g.TW;
-    const float* base = x + ((size_t)b * C + c) * g.Hin * g.Win;
-    const int r0 = 4 * ty - g.pad, c0 = 4 * tx - g.pad;
+    const GenTile q(g, p);
+    const float* base = x + ((size_t)q.b * C + c) * g.Hin * g.Win + q.in_off;
+    const int r0 = 4 * q.ty - g.pad, c0 = 4 * q.tx - g.pad;
+    const size_t rs = (size_t)g.dh * g.Win;
     float d[6][6], tmp[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int r = r0 + i;
-        const bool rin = r >= 0 && r < g.Hin;
+        const bool rin = r >= 0 && r < q.hs_in;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int cc = c0 + j;
-            d[i][j] = (rin && cc >= 0 && cc < g.Win) ? base[(size_t)r * g.Win + cc] : 0.f;
+            d[i][j] = (rin && cc >= 0 && cc < q.ws_in) ? base[(size_t)r * rs + (size_t)cc * g.dw] : 0.f;
         }
     }
 #pragma unroll
@@ -337,7 +356,8 @@ __global__ __launch_bounds__(256) void wino_output_gen_kernel(const float* __res
                                                               const float* __restrict__ bias, int C, GenGeo g, int P, int Pp) {
     const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
     if (p >= P) return;
-    const int T = g.TH * g.TW, b = p / T, t = p - b * T, ty = t / g.TW, tx = t - ty * g.TW;
+    const GenTile q(g, p);
+    const int ty = q.ty, tx = q.tx;
     const size_t plane = (size_t)C * Pp;
     const float* mp = Mb + (size_t)c * Pp + p;
     const float add = bias ? bias[c] : 0.f;
@@ -350,17 +370,18 @@ __global__ __launch_bounds__(256) void wino_output_gen_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < 4; ++i) tmp[i][j] = o[i];
     }
-    float* yp = y + ((size_t)b * C + c) * g.Ho * g.Wo;
+    float* yp = y + ((size_t)q.b * C + c) * g.Ho * g.Wo + q.out_off;
+    const size_t rs = (size_t)g.dh * g.Wo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 4 * ty + i;
-        if (r >= g.Ho) break;
+        if (r >= q.hs_out) break;
         float o[4];
         at6(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], tmp[i][4], tmp[i][5], o);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int cc = 4 * tx + j;
-            if (cc < g.Wo) yp[(size_t)r * g.Wo + cc] = o[j] + add;
+            if (cc < q.ws_out) yp[(size_t)r * rs + (size_t)cc * g.dw] = o[j] + add;
         }
     }
 }
@@ -376,15 +397,16 @@ __global__ __launch_bounds__(256) void wino_outgrad_gen_kernel(const float* __re
         for (int k = 0; k < XI; ++k) mp[(size_t)k * plane] = 0.f;
         return;
     }
-    const int T = g.TH * g.TW, b = p / T, t = p - b * T, ty = t / g.TW, tx = t - ty * g.TW;
-    const float* yp = dy + ((size_t)b * C + c) * g.Ho * g.Wo;
+    const GenTile q(g, p);
+    const float* yp = dy + ((size_t)q.b * C + c) * g.Ho * g.Wo + q.out_off;
+    const size_t rs = (size_t)g.dh * g.Wo;
     float r[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int rr = 4 * ty + i, cc = 4 * tx + j;
-            r[i][j] = (rr < g.Ho && cc < g.Wo) ? yp[(size_t)rr * g.Wo + cc] : 0.f;
+            const int rr = 4 * q.ty + i, cc = 4 * q.tx + j;
+            r[i][j] = (rr < q.hs_out && cc < q.ws_out) ? yp[(size_t)rr * rs + (size_t)cc * g.dw] : 0.f;
         }
     float tmp[6][4];
 #pragma unroll
@@ -409,15 +431,15 @@ struct GenPlan {
     long U, V, M;
     bool ok;
 };
-GenPlan gen_plan(int B, int Cin, int Cout, int Hin, int Win, int pad) {
+GenPlan gen_plan(int B, int Cin, int Cout, int Hin, int Win, int pad, int dh, int dw) {
     GenPlan q = {};
-    q.g.Hin = Hin; q.g.Win = Win; q.g.pad = pad;
-    q.g.Ho = Hin + 2 * pad - 2; q.g.Wo = Win + 2 * pad - 2;
-    q.ok = B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0 && pad >= 0 && pad <= 2 && q.g.Ho > 0 && q.g.Wo > 0 &&
-           Cin <= 65535 && Cout <= 65535;
+    q.g.Hin = Hin; q.g.Win = Win; q.g.pad = pad; q.g.dh = dh; q.g.dw = dw;
+    q.g.Ho = Hin + (2 * pad - 2) * dh; q.g.Wo = Win + (2 * pad - 2) * dw;
+    q.ok = B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0 && pad >= 0 && pad <= 2 && (dh == 1 || dh == 2) &&
+           (dw == 1 || dw == 2) && q.g.Ho > 0 && q.g.Wo > 0 && Cin <= 65535 && Cout <= 65535;
     if (!q.ok) return q;
-    q.g.TH = (q.g.Ho + 3) / 4; q.g.TW = (q.g.Wo + 3) / 4;
-    const long P = (long)B * q.g.TH * q.g.TW, Pp = (P + 31) / 32 * 32;
+    q.g.TH = ((q.g.Ho + dh - 1) / dh + 3) / 4; q.g.TW = ((q.g.Wo + dw - 1) / dw + 3) / 4;
+    const long P = (long)B * dh * dw * q.g.TH * q.g.TW, Pp = (P + 31) / 32 * 32;
     q.ok = Pp < (1L << 31) && Pp * (long)(Cin > Cout ? Cin : Cout) * XI < (1L << 40);
     q.P = (int)P; q.Pp = (int)Pp;
     q.U = (long)XI * Cout * Cin; q.V = (long)XI * Cin * Pp; q.M = (long)XI * Cout * Pp;
@@ -543,22 +565,23 @@ extern "C" int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* v_ke
 }
 
 
-// ---- any map size, padding 0 / 1 / 2, undilated (see GenGeo) -----------------------------------------------------
-extern "C" long spot_conv3x3_winograd_general_ws_floats(int B, int Cin, int Cout, int Hin, int Win, int pad) {
-    const GenPlan q = gen_plan(B, Cin, Cout, Hin, Win, pad);
+// ---- any map size, sub-map padding 0 / 1 / 2, dilation 1 or 2 per axis (see GenGeo) -----------------------------------------------------
+extern "C" long spot_conv3x3_winograd_general_ws_floats(int B, int Cin, int Cout, int Hin, int Win, int pad, int dil_h,
+                                                        int dil_w) {
+    const GenPlan q = gen_plan(B, Cin, Cout, Hin, Win, pad, dil_h, dil_w);
     return q.ok ? q.U + q.V + q.M : 0;
 }
 
-extern "C" long spot_conv3x3_winograd_general_v_floats(int B, int Cin, int Hin, int Win, int pad) {
-    const GenPlan q = gen_plan(B, Cin, 1, Hin, Win, pad);
+extern "C" long spot_conv3x3_winograd_general_v_floats(int B, int Cin, int Hin, int Win, int pad, int dil_h, int dil_w) {
+    const GenPlan q = gen_plan(B, Cin, 1, Hin, Win, pad, dil_h, dil_w);
     return q.ok ? q.V : 0;
 }
 
 extern "C" int spot_conv3x3_winograd_general_f32(const float* in, const float* w, const float* bias, float* out, float* ws,
                                                  float* v_keep, int B, int Cin, int Cout, int Hin, int Win, int pad,
-                                                 int flip, hipStream_t stream) {
+                                                 int dil_h, int dil_w, int flip, hipStream_t stream) {
     SPOT_CHECK_ARG(in && w && out && ws, "conv3x3_winograd_general: null pointer");
-    const GenPlan q = gen_plan(B, Cin, Cout, Hin, Win, pad);
+    const GenPlan q = gen_plan(B, Cin, Cout, Hin, Win, pad, dil_h, dil_w);
     SPOT_CHECK_ARG(q.ok, "conv3x3_winograd_general: bad shape B=%d Cin=%d Cout=%d H=%d W=%d pad=%d", B, Cin, Cout, Hin, Win, pad);
     SPOT_CHECK_ARG((((uintptr_t)ws | (uintptr_t)v_keep) & 15) == 0, "conv3x3_winograd_general: ws / v_keep must be 16-byte aligned");
     float* U = ws;
@@ -584,9 +607,9 @@ extern "C" int spot_conv3x3_winograd_general_f32(const float* in, const float* w
 
 extern "C" int spot_conv3x3_winograd_general_wgrad_f32(const float* x, const float* v_kept, const float* dy, float* dw,
                                                        float* ws, int B, int Cin, int Cout, int Hin, int Win, int pad,
-                                                       int accumulate, hipStream_t stream) {
+                                                       int dil_h, int dil_w, int accumulate, hipStream_t stream) {
     SPOT_CHECK_ARG((x || v_kept) && dy && dw && ws, "conv3x3_winograd_general_wgrad: null pointer");
-    const GenPlan q = gen_plan(B, Cin, Cout, Hin, Win, pad);
+    const GenPlan q = gen_plan(B, Cin, Cout, Hin, Win, pad, dil_h, dil_w);
     SPOT_CHECK_ARG(q.ok, "conv3x3_winograd_general_wgrad: bad shape");
     SPOT_CHECK_ARG((((uintptr_t)ws | (uintptr_t)v_kept) & 15) == 0, "conv3x3_winograd_general_wgrad: ws / v_kept must be 16-byte aligned");
     float* dU = ws;

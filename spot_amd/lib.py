@@ -82,8 +82,8 @@ SIGNATURES = {
     "spot_channel_scale_f32": [vp, vp, i64, i32, vp],
     "spot_ocean_labels_f32": [vp] * 5 + [i32] * 4 + [f32, i32, vp],
     "spot_ocean_tracker_decode": [vp] * 5 + [f64] * 3 + [i32] * 3 + [vp, vp],
-    "spot_conv3x3_winograd_general_f32": [vp] * 6 + [i32] * 7 + [vp],
-    "spot_conv3x3_winograd_general_wgrad_f32": [vp] * 5 + [i32] * 7 + [vp],
+    "spot_conv3x3_winograd_general_f32": [vp] * 6 + [i32] * 9 + [vp],
+    "spot_conv3x3_winograd_general_wgrad_f32": [vp] * 5 + [i32] * 9 + [vp],
     "spot_crop_resize_u8": [vp, vp, i32, vp],
     "spot_crop_resize_batch_u8": [vp, i32, vp, i32, vp],
     "spot_deform_im2col_f32": [vp] * 3 + [i32] * 12 + [vp],
@@ -130,9 +130,9 @@ def load():
     lib.spot_conv3x3_winograd_wgrad_ws_floats.restype = i64
     lib.spot_conv3x3_winograd_wgrad_ws_floats.argtypes = [i32, i32, i32, i32, i32]
     lib.spot_conv3x3_winograd_general_ws_floats.restype = i64
-    lib.spot_conv3x3_winograd_general_ws_floats.argtypes = [i32] * 6
+    lib.spot_conv3x3_winograd_general_ws_floats.argtypes = [i32] * 8
     lib.spot_conv3x3_winograd_general_v_floats.restype = i64
-    lib.spot_conv3x3_winograd_general_v_floats.argtypes = [i32] * 5
+    lib.spot_conv3x3_winograd_general_v_floats.argtypes = [i32] * 7
     lib.spot_deform_col2im_ws_floats.restype = i64
     lib.spot_deform_col2im_ws_floats.argtypes = [i32] * 10
     for name, args in SIGNATURES.items():

@@ -927,29 +927,32 @@ def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, de
 
 
 class Conv3x3GenFn(torch.autograd.Function):
-    """3x3 / stride 1 / undilated convolution with padding 0, 1 or 2 on a map of any size (optionally with bias) by
-    the Winograd F(4x4, 3x3) path with masked partial tiles: the Siamese head's and backbone's 3x3 convolutions on
-    15x15 ... 63x63 maps (ocean_fusion.py:56-85,126-135; ocean_backbone.py:50-51).  The input gradient is the same
-    path on the output gradient with the filter rotated and padding 2 - pad; the weight gradient is summed in the
-    transformed domain from the kept input transform and added straight into the flat gradient buffer."""
+    """3x3 / stride 1 convolution with dilation 1 or 2 per axis and padding = pad * dilation, pad 0, 1 or 2, on a map
+    of any size (optionally with bias) by the Winograd F(4x4, 3x3) path with masked partial tiles: the Siamese head's
+    and backbone's 3x3 convolutions on 15x15 ... 63x63 maps (ocean_fusion.py:56-85,126-158; ocean_backbone.py:50-51).
+    The input gradient is the same path on the output gradient with the filter rotated and pad 2 - pad; the weight
+    gradient is summed in the transformed domain from the kept input transform and added straight into the flat
+    gradient buffer."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pad):
+    def forward(ctx, x, weight, bias, pad, dil=(1, 1)):
         x = _chk(x.contiguous())
         B, Ci, H, W = x.shape
         Co = weight.shape[0]
+        dh, dw_ = int(dil[0]), int(dil[1])
         L = lib.load()
         dev = x.device
         keep = ctx.needs_input_grad[1]
-        y = torch.empty((B, Co, H + 2 * pad - 2, W + 2 * pad - 2), dtype=torch.float32, device=dev)
-        ws = torch.empty((L.spot_conv3x3_winograd_general_ws_floats(B, Ci, Co, H, W, pad),), dtype=torch.float32, device=dev)
-        v = (torch.empty((L.spot_conv3x3_winograd_general_v_floats(B, Ci, H, W, pad),), dtype=torch.float32, device=dev)
-             if keep else None)
+        y = torch.empty((B, Co, H + (2 * pad - 2) * dh, W + (2 * pad - 2) * dw_), dtype=torch.float32, device=dev)
+        ws = torch.empty((L.spot_conv3x3_winograd_general_ws_floats(B, Ci, Co, H, W, pad, dh, dw_),), dtype=torch.float32,
+                         device=dev)
+        v = (torch.empty((L.spot_conv3x3_winograd_general_v_floats(B, Ci, H, W, pad, dh, dw_),), dtype=torch.float32,
+                         device=dev) if keep else None)
         lib.call("spot_conv3x3_winograd_general_f32", _p(x), _p(weight), _p(bias), _p(y), _p(ws), _p(v), B, Ci, Co, H, W,
-                 int(pad), 0, _st())
+                 int(pad), dh, dw_, 0, _st())
         ctx.save_for_backward(weight, v)
         ctx.params = (weight,)
-        ctx.geo = (B, Ci, Co, H, W, pad)
+        ctx.geo = (B, Ci, Co, H, W, pad, dh, dw_)
         if keep:
             _sink_expect(weight)
         return y
@@ -958,7 +961,7 @@ class Conv3x3GenFn(torch.autograd.Function):
     def backward(ctx, dy):
         weight, v = ctx.saved_tensors
         (pw,) = ctx.params
-        B, Ci, Co, H, W, pad = ctx.geo
+        B, Ci, Co, H, W, pad, dh, dw_ = ctx.geo
         dy = dy.contiguous()
         L = lib.load()
         dev = dy.device
@@ -968,20 +971,21 @@ class Conv3x3GenFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             Ho, Wo = dy.shape[2:]
             dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=dev)
-            ws = torch.empty((L.spot_conv3x3_winograd_general_ws_floats(B, Co, Ci, Ho, Wo, 2 - pad),), dtype=torch.float32,
-                             device=dev)
+            ws = torch.empty((L.spot_conv3x3_winograd_general_ws_floats(B, Co, Ci, Ho, Wo, 2 - pad, dh, dw_),),
+                             dtype=torch.float32, device=dev)
             lib.call("spot_conv3x3_winograd_general_f32", _p(dy), _p(weight), None, _p(dx), _p(ws), None, B, Co, Ci, Ho, Wo,
-                     int(2 - pad), 1, _st())
+                     int(2 - pad), dh, dw_, 1, _st())
         if ctx.needs_input_grad[1]:
             sk = _sink(pw)
             dw = sk if sk is not None else torch.empty_like(weight)
-            ws = torch.empty((L.spot_conv3x3_winograd_general_ws_floats(B, Ci, Co, H, W, pad),), dtype=torch.float32, device=dev)
+            ws = torch.empty((L.spot_conv3x3_winograd_general_ws_floats(B, Ci, Co, H, W, pad, dh, dw_),), dtype=torch.float32,
+                             device=dev)
             lib.call("spot_conv3x3_winograd_general_wgrad_f32", None, _p(v), _p(dy), _p(dw), _p(ws), B, Ci, Co, H, W, int(pad),
-                     int(sk is not None), _st())
+                     dh, dw_, int(sk is not None), _st())
             if sk is not None:
                 dw = None
                 _sink_done(pw)
-        return dx, dw, dbias, None
+        return dx, dw, dbias, None, None
 
 
 WINOGRAD_GENERAL = os.environ.get("SPOT_WINOGRAD_GENERAL", "1") == "1"
@@ -996,10 +1000,11 @@ def conv_general(x, conv):
     if (OWN_CONV_IM2COL and x.is_cuda and conv.groups == 1 and s[0] == s[1] and isinstance(p, tuple) and p[0] == p[1]
             and conv.padding_mode == "zeros" and x.dtype == torch.float32):
         kh, kw = conv.kernel_size
-        if (WINOGRAD_GENERAL and (kh, kw) == (3, 3) and s[0] == 1 and tuple(d) == (1, 1) and p[0] in (0, 1, 2)
-                and x.shape[2] + 2 * p[0] > 2 and x.shape[3] + 2 * p[0] > 2 and conv.weight.shape[0] >= 16
-                and conv.weight.shape[1] >= 16):
-            return Conv3x3GenFn.apply(x, conv.weight, conv.bias, p[0])
+        if (WINOGRAD_GENERAL and (kh, kw) == (3, 3) and s[0] == 1 and d[0] in (1, 2) and d[1] in (1, 2)
+                and (p[0] == 0 or (d[0] == d[1] and p[0] in (d[0], 2 * d[0])))
+                and x.shape[2] + 2 * p[0] > 2 * d[0] and x.shape[3] + 2 * p[0] > 2 * d[1]
+                and conv.weight.shape[0] >= 16 and conv.weight.shape[1] >= 16):
+            return Conv3x3GenFn.apply(x, conv.weight, conv.bias, p[0] // d[0], (d[0], d[1]))
         Ho = (x.shape[2] + 2 * p[0] - d[0] * (kh - 1) - 1) // s[0] + 1
         Wo = (x.shape[3] + 2 * p[0] - d[1] * (kw - 1) - 1) // s[0] + 1
         if Ho > 0 and Wo > 0:

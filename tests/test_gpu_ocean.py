@@ -284,16 +284,24 @@ def test_align_head_and_fusion_pipeline(ops, golden):
     assert float(tower.cls_pred.weight.grad.abs().max() if tower.cls_pred.weight.grad is not None else 0.0) == 0.0
 
 
-@pytest.mark.parametrize("hw,pad,bias,B", [((31, 31), 0, False, 3), ((25, 25), 1, True, 3), ((7, 7), 0, False, 5),
-                                           ((3, 3), 0, False, 2), ((63, 63), 1, False, 2), ((29, 27), 1, True, 1),
-                                           ((15, 15), 2, False, 4), ((16, 16), 1, False, 2)])
-def test_winograd_any_size_matches_aten(ops, hw, pad, bias, B):
+@pytest.mark.parametrize("hw,pad,dil,bias,B", [((31, 31), 0, (1, 1), False, 3), ((25, 25), 1, (1, 1), True, 3),
+                                               ((7, 7), 0, (1, 1), False, 5), ((3, 3), 0, (1, 1), False, 2),
+                                               ((63, 63), 1, (1, 1), False, 2), ((29, 27), 1, (1, 1), True, 1),
+                                               ((15, 15), 2, (1, 1), False, 4), ((16, 16), 1, (1, 1), False, 2),
+                                               ((31, 31), 0, (2, 1), False, 3), ((29, 31), 0, (1, 2), False, 2),
+                                               ((7, 7), 0, (2, 1), False, 4), ((7, 7), 0, (1, 2), True, 4),
+                                               ((31, 31), 1, (2, 2), False, 2), ((15, 15), 1, (2, 2), False, 3),
+                                               ((32, 32), 1, (2, 2), False, 1)])
+def test_winograd_any_size_matches_aten(ops, hw, pad, dil, bias, B):
     """Winograd F(4x4, 3x3) with masked partial tiles: forward, input, weight and bias gradients against float64 ATen
-    for map sides that are not multiples of 4, padding 0 / 1 / 2, tile counts that are not multiples of 32."""
+    for map sides that are not multiples of 4, padding 0 / 1 / 2 (times the dilation), dilation 2 along one or both
+    axes (polyphase sub-maps of unequal size on odd maps), tile counts that are not multiples of 32."""
     Ci, Co = 24, 20
-    conv = torch.nn.Conv2d(Ci, Co, 3, padding=pad, bias=bias)
+    padding = (pad * dil[0], pad * dil[1])
+    assert padding[0] == padding[1]
+    conv = torch.nn.Conv2d(Ci, Co, 3, padding=padding, dilation=dil, bias=bias)
     x = T(det_input("x", (B, Ci) + hw, 15, -1, 1))
-    ref = torch.nn.Conv2d(Ci, Co, 3, padding=pad, bias=bias).double()
+    ref = torch.nn.Conv2d(Ci, Co, 3, padding=padding, dilation=dil, bias=bias).double()
     ref.load_state_dict({n: v.double() for n, v in conv.state_dict().items()})
     xr = x.double().requires_grad_()
     yr = ref(xr)
@@ -301,7 +309,7 @@ def test_winograd_any_size_matches_aten(ops, hw, pad, bias, B):
     (yr * up.double()).sum().backward()
     conv = conv.to(DEV)
     xg = x.to(DEV).requires_grad_()
-    y = ops.Conv3x3GenFn.apply(xg, conv.weight, conv.bias, pad)
+    y = ops.Conv3x3GenFn.apply(xg, conv.weight, conv.bias, pad, dil)
     assert y.shape == yr.shape
     (y * up.to(DEV)).sum().backward()
     _close(y, yr.detach().numpy(), 3e-5, "y")
@@ -309,8 +317,9 @@ def test_winograd_any_size_matches_aten(ops, hw, pad, bias, B):
     _close(conv.weight.grad, ref.weight.grad.numpy(), 3e-5, "dw")
     if bias:
         _close(conv.bias.grad, ref.bias.grad.numpy(), 2e-6, "db")
-    # conv_general picks this path for such a convolution and agrees with the patch-matrix path
+    # conv_general picks this path for such a convolution; the patch-matrix path is a separate implementation
     with torch.no_grad():
         a = ops.conv_general(x.to(DEV), conv)
-        b = ops.ConvIm2colFn.apply(x.to(DEV), conv.weight, 1, pad, (1, 1), conv.bias)
+        b = ops.ConvIm2colFn.apply(x.to(DEV), conv.weight, 1, padding[0], dil, conv.bias)
+    assert torch.equal(a, y.detach())
     _close(a, b.cpu().numpy(), 3e-5, "two paths")
