@@ -7,8 +7,12 @@ else: the product path (spot_amd/) never imports it and has no CPU fallback.
 Every function restates, in plain functional torch-CPU / numpy arithmetic on a
 state dict, what one piece of the reference computes, and cites the reference
 file:line it follows (paths relative to the reference checkout).  The oracle is
-pinned: tests/test_oracle_golden.py checks every function here against golden
+pinned: tests/test_oracle_golden.py checks the functions here against golden
 vectors produced by running the reference itself (tests/golden/make_golden.py).
+Two functions are PARITY UNPINNED, because what they restate cannot run here and
+the reference holds no fixture for it: `deform_conv` (the reference's compiled
+deformable-convolution extension) and `resize_linear_u8` (cv2.resize; cv2 is not
+installed).  Both say so where they are defined.
 
 Layout conventions: images NCHW; token tensors batch-first [B, L, C] (the
 reference uses [L, B, C]; the permutation is applied at the boundaries only).
