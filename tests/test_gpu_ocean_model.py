@@ -198,3 +198,46 @@ def test_ocean_tracker_update_and_crop_golden():
             assert np.isfinite(out["target_bbox"]).all() and out["target_bbox"][2] >= 10 and 0 <= out["best_score"] <= 1
         runs.append(np.array([o["target_bbox"] + [float(o["best_score"])] for o in outs]))
     np.testing.assert_array_equal(runs[0], runs[1])
+
+
+def test_ocean_step_with_flat_gradient_buffer_matches_plain_autograd():
+    """The student in flat parameter storage with gradients attached to one flat buffer (kernels add weight
+    gradients straight into it): the same sparse-supervised step gives the same loss and the same gradients as
+    plain autograd, and one fused AdamW step moves every trainable parameter."""
+    from spot_amd import ocean
+    from spot_amd.arena import ParamArena
+    from spot_amd.ocean_model import OceanSparseActor, ocean_resnet50
+    from spot_amd.optim import FlatAdamW
+    S = _settings()
+    crit = ocean.ocean_loss(S)
+    sup, sp = _pair("template", "search", 2, 12), _pair("relay", "aug", 2, 13)
+    sup["masks"] = torch.zeros(2, dtype=torch.bool, device=DEV)
+    sp["masks"] = torch.ones(2, dtype=torch.bool, device=DEV)
+    results = []
+    for flat in (False, True):
+        student = det_fill_positive_norm_(ocean_resnet50(_settings(device="cpu"), "student"), 5).to(DEV).train()
+        teacher = det_fill_positive_norm_(ocean_resnet50(_settings(device="cpu"), "teacher"), 6).to(DEV)
+        arena = None
+        if flat:
+            arena = ParamArena(student)
+            student._spot_arena = arena
+            arena.attach_grads()
+            arena.zero_grad()
+        actor = OceanSparseActor(S, student, teacher, crit)
+        loss, _ = actor(mode="spsup", burnin_data=TensorDict(dict(sup)), sp_data=TensorDict(dict(sp)))
+        loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in student.named_parameters() if p.grad is not None}
+        results.append((float(loss.detach()), grads))
+        if flat:
+            opt = FlatAdamW([{"params": [p for p in student.parameters() if p.requires_grad]}], arena, lr=1e-3, weight_decay=1e-4)
+            before = arena.flat.clone()
+            opt.step()
+            moved = (arena.flat != before).float().mean().item()
+            assert moved > 0.9, moved
+    (l0, g0), (l1, g1) = results
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    assert set(g0) == set(g1)
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for n in g0:                 # gradients that are zero up to rounding (a bias in front of batch statistics) get the global floor
+        scale = float(g0[n].abs().max())
+        assert float((g0[n] - g1[n]).abs().max()) <= 2e-5 * scale + 1e-7 * gmax, n
