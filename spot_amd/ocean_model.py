@@ -248,7 +248,8 @@ def ocean_resnet50(settings, network="student"):
 
 class OceanSparseActor(TranstSparseActor):
     """ocean_sparse_actor.py:10-243: modes "update" (EMA teacher: one streaming kernel over the flat parameter
-    storage, as for SP-TransT), "inference" (teacher pseudo-labels), "burnin", "spsup"."""
+    storage, as for SP-TransT), "inference" (teacher pseudo-labels), "burnin", "spsup".  The statistics are returned
+    as device scalars (the reference calls .item() on each, ten host synchronisations per iteration)."""
 
     def __init__(self, settings, student_net, teacher_net, objective):
         super().__init__(settings, student_net, teacher_net, objective)
@@ -292,10 +293,11 @@ class OceanSparseActor(TranstSparseActor):
         outputs = self.student_net(burnin_data=burnin_data)
         loss_dict = self.objective(outputs, self._build_targets(burnin_data, outputs, "search"), tag="sup")
         losses = self._weighted(loss_dict, "_sup")
-        stats = {"Loss/total": losses.item(), "Loss/ce": loss_dict["loss_ce"].item(), "Loss/bbox": loss_dict["loss_bbox"].item(),
-                 "Loss/align": loss_dict["loss_align"].item(), "iou": loss_dict["iou"].item()}
+        stats = {"Loss/total": losses.detach(), "Loss/ce": loss_dict["loss_ce"].detach(),
+                 "Loss/bbox": loss_dict["loss_bbox"].detach(), "Loss/align": loss_dict["loss_align"].detach(),
+                 "iou": loss_dict["iou"].detach()}
         if "loss_iou_pred" in loss_dict:
-            stats["Loss/iou_pred"] = loss_dict["loss_iou_pred"].item()
+            stats["Loss/iou_pred"] = loss_dict["loss_iou_pred"].detach()
         return losses, stats
 
     def _sp_training(self, burnin_data, sp_data):
@@ -307,13 +309,13 @@ class OceanSparseActor(TranstSparseActor):
         d_unsup = self.objective({k: v for k, v in outputs.items() if k.endswith("_unsup")},
                                  self._build_targets(sp_data, outputs, "aug"), tag="unsup")
         losses = (float(n_sup) * self._weighted(d_sup, "_sup") + float(n_unsup) * self._weighted(d_unsup, "_unsup")) / n
-        stats = {"Loss/total": losses.item(), "iou_sup": d_sup["iou"].item(), "iou_unsup": d_unsup["iou"].item()}
+        stats = {"Loss/total": losses.detach(), "iou_sup": d_sup["iou"].detach(), "iou_unsup": d_unsup["iou"].detach()}
         for key, name in (("loss_ce", "Loss/ce"), ("loss_bbox", "Loss/bbox"), ("loss_align", "Loss/align"),
                           ("loss_iou_pred", "Loss/iou_pred"), ("iou", "iou")):
             if key not in d_sup:
                 continue
-            stats[name] = (d_sup[key].item() if key not in d_unsup else
-                           (float(n_sup) * d_sup[key].item() + float(n_unsup) * d_unsup[key].item()) / n)
+            stats[name] = (d_sup[key].detach() if key not in d_unsup else
+                           (float(n_sup) * d_sup[key].detach() + float(n_unsup) * d_unsup[key].detach()) / n)
         return losses, stats
 
     def __call__(self, mode, teacher_data=None, burnin_data=None, sp_data=None, keep_rate=0.998):

@@ -241,3 +241,33 @@ def test_ocean_step_with_flat_gradient_buffer_matches_plain_autograd():
     for n in g0:                 # gradients that are zero up to rounding (a bias in front of batch statistics) get the global floor
         scale = float(g0[n].abs().max())
         assert float((g0[n] - g1[n]).abs().max()) <= 2e-5 * scale + 1e-7 * gmax, n
+
+
+def test_ocean_trainer_iteration_end_to_end():
+    """LTRSparseTrainer with the Siamese variant: teacher pseudo labels -> middleware filter -> compaction -> student
+    step with gradients in the flat buffer -> fused AdamW, then an EMA update; nothing but the kept count and the
+    loss's finiteness is read by the host."""
+    from spot_amd import ocean
+    from spot_amd.middleware import SparseMiddleware
+    from spot_amd.ocean_model import OceanSparseActor, ocean_resnet50
+    from spot_amd.optim import FlatAdamW
+    from spot_amd.synthetic import sup_batch, unsup_batch
+    from spot_amd.trainer import LTRSparseTrainer
+    S = _settings(batch_size_sup=2, batch_size_unsup=4, teacher_update_frequency=2, keep_rate=0.9)
+    S.curriculum_settings["confidence_threshold"] = 0.0
+    S.batch_size = 6
+    student = det_fill_positive_norm_(ocean_resnet50(_settings(device="cpu"), "student"), 5).to(DEV)
+    teacher = det_fill_positive_norm_(ocean_resnet50(_settings(device="cpu"), "teacher"), 5).to(DEV)
+    actor = OceanSparseActor(S, student, teacher, ocean.ocean_loss(S))
+    trainer = LTRSparseTrainer(actor, None, None, S, SparseMiddleware(S))
+    trainer.arena.attach_grads()
+    trainer.optimizer = FlatAdamW([{"params": [p for p in student.parameters() if p.requires_grad]}], trainer.arena,
+                                  lr=1e-4, weight_decay=1e-4)
+    w0 = student.connect_model.bbox_pred.weight.detach().clone()
+    t0 = next(teacher.parameters()).detach().clone()
+    for i in range(2):
+        data_unsup, mid = unsup_batch(4, 3 + i, temp_sz=127, search_sz=255, device=DEV)
+        stats = trainer.train_iteration(i, sup_batch(2, 3 + i, temp_sz=127, search_sz=255, device=DEV), data_unsup, mid)
+        assert stats is not None and torch.isfinite(stats["Loss/total"])
+    assert not torch.equal(w0, student.connect_model.bbox_pred.weight.detach())
+    assert not torch.equal(t0, next(teacher.parameters()).detach())          # iteration 1 began with an EMA update
