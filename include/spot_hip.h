@@ -219,14 +219,16 @@ int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* v_kept, const f
  * (the 3x3 convolutions of the Siamese head and backbone on 15x15 ... 63x63 maps, some dilated along one axis only:
  * ltr/models/neck/ocean_fusion.py:56-85,126-158, ltr/models/backbone/ocean_backbone.py:50-51): in [B,Cin,Hin,Win] ->
  * out [B,Cout,Hin+(2pad-2)dil_h,Win+(2pad-2)dil_w], bias [Cout] or NULL added on the way out.  flip = 1 with
- * pad' = 2 - pad on the output gradient gives the input gradient.  v_keep (or NULL):
- * spot_conv3x3_winograd_general_v_floats(...) floats receiving the transformed input for the weight gradient.
+ * pad' = 2 - pad on the output gradient gives the input gradient.  opts as for spot_conv3x3_winograd_f32: v_keep
+ * (spot_conv3x3_winograd_general_v_floats(...) floats) receives the transformed input for the weight gradient,
+ * u_keep / u_valid keep the transformed weights across calls, bn_* / relu fold inference BatchNorm (+ ReLU) of the
+ * output channel into the output transform (applied after the bias).
  * The weight gradient takes x (or the kept v) and dy [B,Cout,Ho,Wo]; accumulate = 1 adds into dw. */
 long spot_conv3x3_winograd_general_ws_floats(int B, int Cin, int Cout, int Hin, int Win, int pad, int dil_h, int dil_w);
 long spot_conv3x3_winograd_general_v_floats(int B, int Cin, int Hin, int Win, int pad, int dil_h, int dil_w);
 int spot_conv3x3_winograd_general_f32(const float* in, const float* w, const float* bias, float* out, float* ws,
-                                      float* v_keep, int B, int Cin, int Cout, int Hin, int Win, int pad, int dil_h,
-                                      int dil_w, int flip, hipStream_t stream);
+                                      const spot_winograd_opts* opts /* host, may be NULL */, int B, int Cin, int Cout,
+                                      int Hin, int Win, int pad, int dil_h, int dil_w, int flip, hipStream_t stream);
 int spot_conv3x3_winograd_general_wgrad_f32(const float* x, const float* v_kept, const float* dy, float* dw, float* ws,
                                             int B, int Cin, int Cout, int Hin, int Win, int pad, int dil_h, int dil_w,
                                             int accumulate, hipStream_t stream);

@@ -353,9 +353,15 @@ __global__ __launch_bounds__(256) void wino_input_gen_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void wino_output_gen_kernel(const float* __restrict__ Mb, float* __restrict__ y,
-                                                              const float* __restrict__ bias, int C, GenGeo g, int P, int Pp) {
+                                                              const float* __restrict__ bias, int C, GenGeo g, int P, int Pp,
+                                                              OutAffine bn) {
     const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
     if (p >= P) return;
+    float sc = 1.f, sh = 0.f;
+    if (bn.gamma) {                              // same arithmetic as the stand-alone inference kernel
+        sc = bn.gamma[c] / sqrtf(bn.var[c] + bn.eps);
+        sh = bn.beta[c] - bn.mean[c] * sc;
+    }
     const GenTile q(g, p);
     const int ty = q.ty, tx = q.tx;
     const size_t plane = (size_t)C * Pp;
@@ -381,7 +387,14 @@ __global__ __launch_bounds__(256) void wino_output_gen_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int cc = 4 * tx + j;
-            if (cc < q.ws_out) yp[(size_t)r * rs + (size_t)cc * g.dw] = o[j] + add;
+            if (cc < q.ws_out) {
+                float v = o[j] + add;
+                if (bn.gamma) {
+                    v = fmaf(v, sc, sh);
+                    if (bn.relu) v = fmaxf(v, 0.f);
+                }
+                yp[(size_t)r * rs + (size_t)cc * g.dw] = v;
+            }
         }
     }
 }
@@ -578,17 +591,27 @@ extern "C" long spot_conv3x3_winograd_general_v_floats(int B, int Cin, int Hin, 
 }
 
 extern "C" int spot_conv3x3_winograd_general_f32(const float* in, const float* w, const float* bias, float* out, float* ws,
-                                                 float* v_keep, int B, int Cin, int Cout, int Hin, int Win, int pad,
-                                                 int dil_h, int dil_w, int flip, hipStream_t stream) {
+                                                 const spot_winograd_opts* opts, int B, int Cin, int Cout, int Hin,
+                                                 int Win, int pad, int dil_h, int dil_w, int flip, hipStream_t stream) {
+    float* v_keep = opts ? opts->v_keep : nullptr;
+    float* u_keep = opts ? opts->u_keep : nullptr;
+    OutAffine bn = {nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+    if (opts && opts->bn_gamma) {
+        SPOT_CHECK_ARG(opts->bn_beta && opts->bn_mean && opts->bn_var, "conv3x3_winograd_general: bn_gamma needs bn_beta, bn_mean, bn_var");
+        bn = {opts->bn_gamma, opts->bn_beta, opts->bn_mean, opts->bn_var, opts->bn_eps, opts->relu};
+    }
     SPOT_CHECK_ARG(in && w && out && ws, "conv3x3_winograd_general: null pointer");
     const GenPlan q = gen_plan(B, Cin, Cout, Hin, Win, pad, dil_h, dil_w);
     SPOT_CHECK_ARG(q.ok, "conv3x3_winograd_general: bad shape B=%d Cin=%d Cout=%d H=%d W=%d pad=%d", B, Cin, Cout, Hin, Win, pad);
-    SPOT_CHECK_ARG((((uintptr_t)ws | (uintptr_t)v_keep) & 15) == 0, "conv3x3_winograd_general: ws / v_keep must be 16-byte aligned");
-    float* U = ws;
+    SPOT_CHECK_ARG((((uintptr_t)ws | (uintptr_t)v_keep | (uintptr_t)u_keep) & 15) == 0,
+                   "conv3x3_winograd_general: ws / v_keep / u_keep must be 16-byte aligned");
+    float* U = u_keep ? u_keep : ws;
     float* V = v_keep ? v_keep : ws + q.U;
     float* Mb = ws + q.U + q.V;
-    wino_weights_kernel<<<spot_ceil_div((long)Cout * Cin, 256), 256, 0, stream>>>(w, U, Cout, Cin, flip);
-    SPOT_CHECK_LAUNCH("conv3x3_winograd_general(weights)");
+    if (!(u_keep && opts->u_valid)) {
+        wino_weights_kernel<<<spot_ceil_div((long)Cout * Cin, 256), 256, 0, stream>>>(w, U, Cout, Cin, flip);
+        SPOT_CHECK_LAUNCH("conv3x3_winograd_general(weights)");
+    }
     wino_input_gen_kernel<<<dim3(spot_ceil_div(q.Pp, 256), Cin), 256, 0, stream>>>(in, V, Cin, q.g, q.P, q.Pp);
     SPOT_CHECK_LAUNCH("conv3x3_winograd_general(input)");
     spot_gemm_desc d = {};
@@ -600,7 +623,7 @@ extern "C" int spot_conv3x3_winograd_general_f32(const float* in, const float* w
     d.splitk = 1; d.alpha = 1.f;
     const int rc = spot_gemm_f32(&d, stream);
     if (rc != SPOT_OK) return rc;
-    wino_output_gen_kernel<<<dim3(spot_ceil_div(q.P, 256), Cout), 256, 0, stream>>>(Mb, out, bias, Cout, q.g, q.P, q.Pp);
+    wino_output_gen_kernel<<<dim3(spot_ceil_div(q.P, 256), Cout), 256, 0, stream>>>(Mb, out, bias, Cout, q.g, q.P, q.Pp, bn);
     SPOT_CHECK_LAUNCH("conv3x3_winograd_general(output)");
     return SPOT_OK;
 }

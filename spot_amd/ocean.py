@@ -22,7 +22,7 @@ def _conv_bn_relu(seq, x):
     mods = list(seq)
     assert len(mods) % 3 == 0
     for i in range(0, len(mods), 3):
-        x = ops.batch_norm_act(ops.conv_general(x, mods[i]), mods[i + 1], relu=True)
+        x = ops.conv_bn_act(x, mods[i], mods[i + 1], relu=True)
     return x
 
 

@@ -44,7 +44,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         out = ops.batch_norm_act(ops.conv_general(x, self.conv1), self.bn1, relu=True)
-        out = ops.batch_norm_act(ops.conv_general(out, self.conv2), self.bn2, relu=True)
+        out = ops.conv_bn_act(out, self.conv2, self.bn2, relu=True)
         residual = x
         if self.downsample is not None:
             residual = ops.batch_norm_act(ops.conv_general(x, self.downsample[0]), self.downsample[1])

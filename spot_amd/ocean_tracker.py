@@ -88,7 +88,9 @@ class Ocean_Tracker(object):
         s_z = round(np.sqrt(wc_z * hc_z))
         avg_chans = (image.float().mean(dim=(0, 1)).cpu().numpy() if torch.is_tensor(image) else np.mean(image, axis=(0, 1)))
         z_crop = self.get_subwindow_tracking(image, target_pos, p.exemplar_size, s_z, avg_chans)
-        with torch.no_grad():
+        if isinstance(self.net, torch.nn.Module):
+            ops.frozen_weights.forget(self.net)     # the network may have been trained since the last sequence
+        with torch.no_grad(), ops.frozen_weights():     # transformed convolution weights are kept across frames
             self.net.template(self._normalize(z_crop))
         if p.windowing == "cosine":
             window = np.outer(np.hanning(p.score_size), np.hanning(p.score_size))
@@ -144,7 +146,7 @@ class Ocean_Tracker(object):
 
     def update(self, net, x_crops, target_pos, target_sz, window, scale_z, p):
         """ocean_tracker.py:71-130."""
-        with torch.no_grad():
+        with torch.no_grad(), ops.frozen_weights():
             tgt = torch.tensor([float(target_sz[0]), float(target_sz[1])], dtype=torch.float64)
             if self._target_dev is None:
                 self._target_dev = tgt.cuda()

@@ -948,8 +948,12 @@ class Conv3x3GenFn(torch.autograd.Function):
                          device=dev)
         v = (torch.empty((L.spot_conv3x3_winograd_general_v_floats(B, Ci, H, W, pad, dh, dw_),), dtype=torch.float32,
                          device=dev) if keep else None)
-        lib.call("spot_conv3x3_winograd_general_f32", _p(x), _p(weight), _p(bias), _p(y), _p(ws), _p(v), B, Ci, Co, H, W,
-                 int(pad), dh, dw_, 0, _st())
+        opts = None
+        if v is not None:
+            opts = lib.WinogradOpts()
+            opts.v_keep = v.data_ptr()
+        lib.call("spot_conv3x3_winograd_general_f32", _p(x), _p(weight), _p(bias), _p(y), _p(ws),
+                 C.byref(opts) if opts is not None else None, B, Ci, Co, H, W, int(pad), dh, dw_, 0, _st())
         ctx.save_for_backward(weight, v)
         ctx.params = (weight,)
         ctx.geo = (B, Ci, Co, H, W, pad, dh, dw_)
@@ -988,6 +992,48 @@ class Conv3x3GenFn(torch.autograd.Function):
         return dx, dw, dbias, None, None
 
 
+def _winograd_general_applies(x, conv):
+    s, p, d = conv.stride, conv.padding, conv.dilation
+    return (WINOGRAD_GENERAL and x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (3, 3) and conv.groups == 1
+            and s == (1, 1) and isinstance(p, tuple) and p[0] == p[1] and conv.padding_mode == "zeros"
+            and d[0] in (1, 2) and d[1] in (1, 2) and (p[0] == 0 or (d[0] == d[1] and p[0] in (d[0], 2 * d[0])))
+            and x.shape[2] + 2 * p[0] > 2 * d[0] and x.shape[3] + 2 * p[0] > 2 * d[1]
+            and conv.weight.shape[0] >= 16 and conv.weight.shape[1] >= 16)
+
+
+def conv_bn_act(x, conv, bn, relu=False):
+    """[relu](bn(conv(x))) for any nn.Conv2d this library runs.  With `bn` in inference mode and no gradient wanted, a
+    3x3 convolution on the any-size Winograd path takes the normalisation (and ReLU) in its output transform, and
+    keeps its transformed weights inside `with frozen_weights():`; otherwise conv_general -> batch_norm_act."""
+    fold = (not bn.training and bn.track_running_stats and not torch.is_grad_enabled() and _winograd_general_applies(x, conv))
+    if not fold:
+        return batch_norm_act(conv_general(x, conv), bn, relu=relu)
+    x = _chk(x.contiguous())
+    B, Ci, H, W = x.shape
+    weight = conv.weight
+    Co = weight.shape[0]
+    dh, dw_ = conv.dilation
+    pad = conv.padding[0] // dh
+    L = lib.load()
+    y = torch.empty((B, Co, H + (2 * pad - 2) * dh, W + (2 * pad - 2) * dw_), dtype=torch.float32, device=x.device)
+    ws = torch.empty((L.spot_conv3x3_winograd_general_ws_floats(B, Ci, Co, H, W, pad, dh, dw_),), dtype=torch.float32,
+                     device=x.device)
+    opts = lib.WinogradOpts()
+    if frozen_weights._active:
+        key = ("winograd", weight.data_ptr(), tuple(weight.shape), 0)
+        hit = frozen_weights._tables.get(key)
+        opts.u_valid = int(hit is not None)
+        if hit is None:
+            hit = frozen_weights._tables[key] = (torch.empty((36 * Co * Ci,), dtype=torch.float32, device=x.device), weight)
+        opts.u_keep = hit[0].data_ptr()
+    opts.bn_gamma, opts.bn_beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+    opts.bn_mean, opts.bn_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+    opts.bn_eps, opts.relu = float(bn.eps), int(relu)
+    lib.call("spot_conv3x3_winograd_general_f32", _p(x), _p(weight), _p(conv.bias), _p(y), _p(ws), C.byref(opts), B, Ci, Co,
+             H, W, int(pad), int(dh), int(dw_), 0, _st())
+    return y
+
+
 WINOGRAD_GENERAL = os.environ.get("SPOT_WINOGRAD_GENERAL", "1") == "1"
 OWN_CONV_IM2COL = os.environ.get("SPOT_OWN_CONV_IM2COL", "1") == "1"
 
@@ -1000,10 +1046,7 @@ def conv_general(x, conv):
     if (OWN_CONV_IM2COL and x.is_cuda and conv.groups == 1 and s[0] == s[1] and isinstance(p, tuple) and p[0] == p[1]
             and conv.padding_mode == "zeros" and x.dtype == torch.float32):
         kh, kw = conv.kernel_size
-        if (WINOGRAD_GENERAL and (kh, kw) == (3, 3) and s[0] == 1 and d[0] in (1, 2) and d[1] in (1, 2)
-                and (p[0] == 0 or (d[0] == d[1] and p[0] in (d[0], 2 * d[0])))
-                and x.shape[2] + 2 * p[0] > 2 * d[0] and x.shape[3] + 2 * p[0] > 2 * d[1]
-                and conv.weight.shape[0] >= 16 and conv.weight.shape[1] >= 16):
+        if _winograd_general_applies(x, conv):
             return Conv3x3GenFn.apply(x, conv.weight, conv.bias, p[0] // d[0], (d[0], d[1]))
         Ho = (x.shape[2] + 2 * p[0] - d[0] * (kh - 1) - 1) // s[0] + 1
         Wo = (x.shape[3] + 2 * p[0] - d[1] * (kw - 1) - 1) // s[0] + 1
@@ -1339,6 +1382,14 @@ class frozen_weights:
     @staticmethod
     def clear():
         frozen_weights._tables.clear()
+
+    @staticmethod
+    def forget(module):
+        """Drop the entries derived from this module's parameters (after its weights changed) and leave those of
+        other networks, whose captured graphs may still read them."""
+        ptrs = {p.data_ptr() for p in module.parameters()}
+        for key in [k for k in frozen_weights._tables if any(isinstance(e, int) and e in ptrs for e in k)]:
+            del frozen_weights._tables[key]
 
 
 def _pos_table(pos2, W, b):
