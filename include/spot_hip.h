@@ -295,6 +295,14 @@ int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long ldk, const f
                      int Lq, int Lk, int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed,
                      hipStream_t stream);
 
+/* The same forward for grids too small to fill the chip (the online tracker: one clip): the keys are cut in nsplit
+ * ranges, one workgroup each, and merged by a second kernel.  Inference only (no dropout, no lse).  ws:
+ * spot_mha_fwd_splitk_ws_floats(B, Lq, nhead, nsplit) floats. */
+long spot_mha_fwd_splitk_ws_floats(int B, int Lq, int nhead, int nsplit);
+int spot_mha_fwd_splitk_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* out,
+                            long ldo, const unsigned char* key_padding_mask, float* ws, int nsplit, int B, int Lq, int Lk,
+                            int nhead, int head_dim, float scale, hipStream_t stream);
+
 /* Gradient of the above w.r.t. q, k, v given d_out.  delta_ws: workspace [B,nhead,Lq] floats.
  * dq is accumulated with atomic adds and is cleared by this call. */
 int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,

@@ -141,14 +141,17 @@ template <bool BF16>
 __global__ __launch_bounds__(256, 3) void mha_fwd_kernel(
     const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
     float* __restrict__ O, long ldo, float* __restrict__ LSE, const unsigned char* __restrict__ kpm,
-    int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed, float drop_scale) {
+    int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed, float drop_scale,
+    int nsplit = 1, float* __restrict__ part_o = nullptr, float* __restrict__ part_ml = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * KP];
     auto Ks = [&](int buf) { return lds + buf * 2 * KT * KP; };
     auto Vs = [&](int buf) { return lds + buf * 2 * KT * KP + KT * KP; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int head = blockIdx.y, b = blockIdx.z;
-    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    // with nsplit > 1 the keys are cut in nsplit ranges of whole tiles, one workgroup each: blockIdx.x = tile * nsplit + s
+    const int split = (int)blockIdx.x % nsplit;
+    const int q = ((int)blockIdx.x / nsplit) * 128 + wave * 32 + l31;
     const bool qok = q < Lq;
     const float c = scale * 1.4426950408889634f;   // Q is pre-multiplied by c: scores live in the log2 domain
     const unsigned qs = ((unsigned)q << 16) ^ attn_stream_key(drop_seed, (unsigned)(b * H + head));
@@ -189,12 +192,15 @@ __global__ __launch_bounds__(256, 3) void mha_fwd_kernel(
         }
     };
 
-    const int ntile = (Lk + KT - 1) / KT;
-    fetch(0);
-    stash(0);
+    const int ntile_all = (Lk + KT - 1) / KT, per = (ntile_all + nsplit - 1) / nsplit;
+    const int t0 = split * per, ntile = min(ntile_all, t0 + per);
+    if (t0 < ntile) {
+        fetch(t0);
+        stash(0);
+    }
     __syncthreads();
-    for (int t = 0; t < ntile; ++t) {
-        const int cur = t & 1;
+    for (int t = t0; t < ntile; ++t) {
+        const int cur = (t - t0) & 1;
         const bool more = t + 1 < ntile;
         if (more) fetch(t + 1);
 #pragma unroll
@@ -228,6 +234,20 @@ __global__ __launch_bounds__(256, 3) void mha_fwd_kernel(
     }
     // each half summed its own 16 keys per block
     const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if (part_o) {                // this key range's unnormalised sums, its running maximum (log2 domain) and row sum
+        if (qok) {
+            float* op = part_o + (((long)split * gridDim.z + b) * Lq + q) * ((long)H * DH) + head * DH;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<float4*>(op + 8 * gq + 4 * h) = make_float4(o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]);
+            if (h == 0) {
+                float* mp = part_ml + ((((long)split * gridDim.z + b) * H + head) * Lq + q) * 2;
+                mp[0] = m_run;
+                mp[1] = l_tot;
+            }
+        }
+        return;
+    }
     const float inv = 1.f / l_tot;
     if (qok) {
         float* op = O + ((long)b * Lq + q) * ldo + head * DH;
@@ -723,5 +743,66 @@ extern "C" int spot_mha_dropout_mask(unsigned char* mask, int B, int nhead, int 
     SPOT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mha_dropout_mask: drop_p=%f outside [0,1)", drop_p);
     attn_mask_kernel<<<2048, 256, 0, stream>>>(mask, Lq, Lk, B * nhead, spot_drop_threshold(drop_p), drop_seed);
     SPOT_CHECK_LAUNCH("mha_dropout_mask");
+    return SPOT_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// Forward for grids too small to fill the chip (the online tracker: one clip, 8 heads, 2-8 query tiles): the keys
+// are cut in nsplit ranges, one workgroup each, and a second kernel merges the partial softmax sums
+//   m = max_s m_s,  out = sum_s 2^(m_s - m) o_s / sum_s 2^(m_s - m) l_s.
+// Inference only: no dropout, no log-sum-exp output.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void mha_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                        float* __restrict__ O, long ldo, int B, int Lq, int H, int nsplit) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // (b, q, head, group of 4 features)
+    const long total = (long)B * Lq * H * (DH / 4);
+    if (idx >= total) return;
+    const int g4 = (int)(idx % (DH / 4)), head = (int)(idx / (DH / 4) % H);
+    const long row = idx / ((DH / 4) * H);                            // b * Lq + q
+    const int b = (int)(row / Lq), q = (int)(row - (long)b * Lq);
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, part_ml[((((long)s * B + b) * H + head) * Lq + q) * 2]);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float den = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* ml = part_ml + ((((long)s * B + b) * H + head) * Lq + q) * 2;
+        const float w = ml[0] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ml[0] - m);
+        const float4 o = *reinterpret_cast<const float4*>(part_o + (((long)s * B + b) * Lq + q) * ((long)H * DH) + head * DH + 4 * g4);
+        acc.x += w * o.x; acc.y += w * o.y; acc.z += w * o.z; acc.w += w * o.w;
+        den += w * ml[1];
+    }
+    const float inv = 1.f / den;
+    *reinterpret_cast<float4*>(O + row * ldo + head * DH + 4 * g4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+}  // namespace
+
+extern "C" long spot_mha_fwd_splitk_ws_floats(int B, int Lq, int nhead, int nsplit) {
+    if (B <= 0 || Lq <= 0 || nhead <= 0 || nsplit <= 0) return 0;
+    return (long)nsplit * B * Lq * nhead * (DH + 2);
+}
+
+extern "C" int spot_mha_fwd_splitk_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                                       float* out, long ldo, const unsigned char* key_padding_mask, float* ws, int nsplit,
+                                       int B, int Lq, int Lk, int nhead, int head_dim, float scale, hipStream_t stream) {
+    SPOT_CHECK_ARG(q && k && v && out && ws, "mha_fwd_splitk: null pointer");
+    SPOT_CHECK_ARG(head_dim == DH, "mha_fwd_splitk: head_dim=%d unsupported (this build handles 32)", head_dim);
+    SPOT_CHECK_ARG(B >= 0 && Lq > 0 && Lk > 0 && nhead > 0 && nsplit >= 1 && nsplit <= 64,
+                   "mha_fwd_splitk: bad shape B=%d Lq=%d Lk=%d heads=%d nsplit=%d", B, Lq, Lk, nhead, nsplit);
+    SPOT_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 &&
+                       (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)ws) & 15) == 0,
+                   "mha_fwd_splitk: operands must be 16-byte aligned with row strides that are multiples of 4");
+    SPOT_CHECK_ARG(B <= 65535 && nhead <= 65535, "mha_fwd_splitk: B and heads must fit a grid dimension");
+    if (B == 0) return SPOT_OK;
+    float* part_o = ws;
+    float* part_ml = ws + (long)nsplit * B * Lq * nhead * DH;
+    dim3 grid(((Lq + 127) / 128) * nsplit, nhead, B);
+    mha_fwd_kernel<false><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, nullptr, key_padding_mask, Lq, Lk,
+                                                    nhead, scale, 0u, 0u, 1.f, nsplit, part_o, part_ml);
+    SPOT_CHECK_LAUNCH("mha_fwd_splitk");
+    const long total = (long)B * Lq * nhead * (DH / 4);
+    mha_merge_kernel<<<spot_ceil_div(total, 256), 256, 0, stream>>>(part_o, part_ml, out, ldo, B, Lq, nhead, nsplit);
+    SPOT_CHECK_LAUNCH("mha_fwd_splitk(merge)");
     return SPOT_OK;
 }

@@ -93,6 +93,7 @@ SIGNATURES = {
     "spot_conv3x3_winograd_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "spot_conv3x3_winograd_wgrad_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
+    "spot_mha_fwd_splitk_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp] + [i32] * 6 + [f32, vp],
     "spot_mha_bwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64,
                          i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
     "spot_mha_fwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
@@ -133,6 +134,8 @@ def load():
     lib.spot_conv3x3_winograd_general_ws_floats.argtypes = [i32] * 8
     lib.spot_conv3x3_winograd_general_v_floats.restype = i64
     lib.spot_conv3x3_winograd_general_v_floats.argtypes = [i32] * 7
+    lib.spot_mha_fwd_splitk_ws_floats.restype = i64
+    lib.spot_mha_fwd_splitk_ws_floats.argtypes = [i32] * 4
     lib.spot_deform_col2im_ws_floats.restype = i64
     lib.spot_deform_col2im_ws_floats.argtypes = [i32] * 10
     for name, args in SIGNATURES.items():

@@ -200,7 +200,33 @@ def box_iou_pair(b1, b2, cxcywh=False, want_giou=True):
     return giou, iou, uni
 
 
-class GIoUPairFn(torch.autograd.Function):
+
+_GRAD_AT_APPLY = True
+
+
+class _Fn(torch.autograd.Function):
+    """autograd.Function whose forward can tell whether a gradient can be asked for at all: inside forward() grad mode
+    is always off and ctx.needs_input_grad reflects requires_grad only (True for parameters under torch.no_grad()),
+    so the grad mode at the time of apply() is recorded here.  _wants(ctx[, i]) is what forward() should consult
+    before it keeps or computes anything for backward (log-sum-exp, sign bytes, transformed inputs)."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        global _GRAD_AT_APPLY
+        prev, _GRAD_AT_APPLY = _GRAD_AT_APPLY, torch.is_grad_enabled()
+        try:
+            return super().apply(*args, **kwargs)
+        finally:
+            _GRAD_AT_APPLY = prev
+
+
+def _wants(ctx, i=None):
+    if not _GRAD_AT_APPLY:
+        return False
+    return any(ctx.needs_input_grad) if i is None else bool(ctx.needs_input_grad[i])
+
+
+class GIoUPairFn(_Fn):
     """(giou, iou) of paired cxcywh boxes; gradient flows to the first set only."""
 
     @staticmethod
@@ -263,7 +289,7 @@ def crop_resize_batch_u8(frames, windows, pads, out_sz):
 # ---------------------------------------------------------------------------
 # depthwise cross-correlation
 # ---------------------------------------------------------------------------
-class XCorrDepthwiseFn(torch.autograd.Function):
+class XCorrDepthwiseFn(_Fn):
     @staticmethod
     def forward(ctx, x, kernel):
         x, kernel = _chk(x.contiguous()), _chk(kernel.contiguous())
@@ -291,7 +317,7 @@ def xcorr_depthwise(x, kernel):
     return XCorrDepthwiseFn.apply(x, kernel)
 
 
-class GroupDWFn(torch.autograd.Function):
+class GroupDWFn(_Fn):
     @staticmethod
     def forward(ctx, z11, z12, z21, x11, x12, x21, weight):
         ts = [_chk(t.contiguous()) for t in (z11, z12, z21, x11, x12, x21, weight)]
@@ -521,7 +547,7 @@ def colsum(x2, out=None):
     return out
 
 
-class LinearFn(torch.autograd.Function):
+class LinearFn(_Fn):
     """nn.Linear (+ fused ReLU) on [..., K] inputs."""
 
     @staticmethod
@@ -566,7 +592,7 @@ def linear(x, W, b=None, relu=False):
     return LinearFn.apply(x, W, b, relu)
 
 
-class FFNFn(torch.autograd.Function):
+class FFNFn(_Fn):
     """z = x + drop(linear2(drop(relu(linear1(x)))))  — the FFN sublayer with its residual and both
     dropouts (transt_fusion.py:151-152,234-235,240-241).  Dropout masks are regenerated from their
     seeds in backward; the hidden mask and relu' collapse into one test on the stored activation."""
@@ -605,7 +631,7 @@ class FFNFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------
 # LayerNorm
 # ---------------------------------------------------------------------------
-class LayerNormFn(torch.autograd.Function):
+class LayerNormFn(_Fn):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
         x2 = _view2d(x.contiguous())
@@ -656,7 +682,7 @@ def layer_norm_infer(x, gamma, beta, eps=1e-5):
 # ---------------------------------------------------------------------------
 # 1x1 convolutions of the ResNet bottleneck as GEMMs on the NCHW maps
 # ---------------------------------------------------------------------------
-class Conv1x1Fn(torch.autograd.Function):
+class Conv1x1Fn(_Fn):
     """y[b] = W x[b] for a bias-free 1x1 convolution, NCHW in and out (resnet.py:77,83,131-134).
 
     Per clip the feature map is already a [C, H*W] row-major matrix, so forward, input gradient and weight
@@ -758,7 +784,7 @@ def conv1x1_bn_act(x, conv, bn, relu=False, residual=None, passthrough=False):
     return y
 
 
-class ConvIm2colFn(torch.autograd.Function):
+class ConvIm2colFn(_Fn):
     """Convolution as patch matrix + GEMM, for what lies outside the Winograd path: the ResNet's 7x7 / stride 2 stem
     and layer2's 3x3 / stride 2 (resnet.py:61,79,195-196), and the Siamese head's 3x3 convolutions on odd-sized maps,
     some with a bias, some dilated along one axis (ocean_fusion.py:56-85,126-158).  Forward, input gradient (GEMM
@@ -835,7 +861,7 @@ class ConvIm2colFn(torch.autograd.Function):
         return dx, dw, None, None, None, dbias
 
 
-class DeformConvFn(torch.autograd.Function):
+class DeformConvFn(_Fn):
     """Deformable convolution v1, bias-free, one group (dcn/deform_conv.py:12-110 as the aligned head uses it,
     ocean_fusion.py:174-192): the bilinearly sampled patch matrix is built by one kernel, after which forward,
     input-gradient and weight-gradient products are the GEMMs of ConvIm2colFn; one more kernel scatters the patch
@@ -926,7 +952,7 @@ def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, de
     return DeformConvFn.apply(x, offset, weight, stride, padding, dilation, deformable_groups)
 
 
-class Conv3x3GenFn(torch.autograd.Function):
+class Conv3x3GenFn(_Fn):
     """3x3 / stride 1 convolution with dilation 1 or 2 per axis and padding = pad * dilation, pad 0, 1 or 2, on a map
     of any size (optionally with bias) by the Winograd F(4x4, 3x3) path with masked partial tiles: the Siamese head's
     and backbone's 3x3 convolutions on 15x15 ... 63x63 maps (ocean_fusion.py:56-85,126-158; ocean_backbone.py:50-51).
@@ -942,7 +968,7 @@ class Conv3x3GenFn(torch.autograd.Function):
         dh, dw_ = int(dil[0]), int(dil[1])
         L = lib.load()
         dev = x.device
-        keep = ctx.needs_input_grad[1]
+        keep = _wants(ctx, 1)
         y = torch.empty((B, Co, H + (2 * pad - 2) * dh, W + (2 * pad - 2) * dw_), dtype=torch.float32, device=dev)
         ws = torch.empty((L.spot_conv3x3_winograd_general_ws_floats(B, Ci, Co, H, W, pad, dh, dw_),), dtype=torch.float32,
                          device=dev)
@@ -1055,7 +1081,7 @@ def conv_general(x, conv):
     return conv(x)
 
 
-class MaxPool3x3s2Fn(torch.autograd.Function):
+class MaxPool3x3s2Fn(_Fn):
     """nn.MaxPool2d(3, stride=2, padding=1) (resnet.py:113,199): one byte per output remembers the winning window
     position, the backward gathers through it."""
 
@@ -1064,7 +1090,7 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         x = _chk(x.contiguous())
         B, Cn, H, W = x.shape
         y = torch.empty((B, Cn, H // 2, W // 2), dtype=torch.float32, device=x.device)
-        win = torch.empty((B, Cn, H // 2, W // 2), dtype=torch.uint8, device=x.device) if ctx.needs_input_grad[0] else None
+        win = torch.empty((B, Cn, H // 2, W // 2), dtype=torch.uint8, device=x.device) if _wants(ctx, 0) else None
         lib.call("spot_maxpool3x3s2_fwd_f32", _p(x), _p(y), _p(win), B * Cn, H, W, _st())
         ctx.save_for_backward(win)
         ctx.shape = (B, Cn, H, W)
@@ -1125,7 +1151,7 @@ def _winograd(inp, weight, Cout, flip, dilation=1, keep_v=False, bn=None, relu=F
     return (out, v) if keep_v else out
 
 
-class Conv3x3Fn(torch.autograd.Function):
+class Conv3x3Fn(_Fn):
     """Bias-free 3x3 convolution, stride 1, padding 1 (resnet.py:79-81): forward and input gradient by the
     Winograd F(4x4, 3x3) path of the library; the weight gradient likewise (summed in the transformed domain and
     added straight into the flat gradient buffer), or by the convolution library with SPOT_WINOGRAD_WGRAD=0."""
@@ -1133,7 +1159,7 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, dilation=1):
         x = _chk(x.contiguous())
-        keep = ctx.needs_input_grad[1] and _WINOGRAD_WGRAD        # the transformed input serves the weight gradient too
+        keep = _wants(ctx, 1) and _WINOGRAD_WGRAD        # the transformed input serves the weight gradient too
         y = _winograd(x, weight, weight.shape[0], False, dilation, keep_v=keep)
         y, v = y if keep else (y, None)
         ctx.save_for_backward(None if keep else x, weight, v)
@@ -1209,7 +1235,7 @@ def conv3x3_bn_act(x, conv, bn, relu=False):
 # ---------------------------------------------------------------------------
 # BatchNorm2d + ReLU (+ residual) of the ResNet bottleneck
 # ---------------------------------------------------------------------------
-class BatchNormActFn(torch.autograd.Function):
+class BatchNormActFn(_Fn):
     """y = [relu](batch_norm(x) [+ residual]) in training mode (batch statistics, running stats updated)."""
 
     @staticmethod
@@ -1224,7 +1250,7 @@ class BatchNormActFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty((Cn,), dtype=torch.float32, device=dev)
         rstd = torch.empty((Cn,), dtype=torch.float32, device=dev)
-        need = any(ctx.needs_input_grad)
+        need = _wants(ctx)
         # one byte per pack of four elements, or per element on maps whose H*W is not a multiple of 4
         sign = (torch.empty((x.numel() // 4 if HW % 4 == 0 else x.numel(),), dtype=torch.uint8, device=dev)
                 if (relu and need) else None)
@@ -1340,11 +1366,32 @@ def batch_norm_act(x, bn, relu=False, residual=None):
 # ---------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------
+_MHA_SPLITK = os.environ.get("SPOT_MHA_SPLITK", "1") == "1"
+
+
+def _mha_key_splits(B, Lq, Lk, nhead):
+    """Key ranges per query tile for an inference forward whose grid of (query tile, head, clip) workgroups would
+    leave most of the 256 CUs idle (the online tracker: one clip): enough ranges of whole 64-key tiles to reach a few
+    hundred workgroups, at most 8."""
+    if not _MHA_SPLITK:
+        return 1
+    wgs = (Lq + 127) // 128 * nhead * B
+    if wgs >= 128:
+        return 1
+    return max(1, min((Lk + 63) // 64, 8, 384 // wgs))
+
+
 def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, out=None, drop_p=0.0, drop_seed=0,
                  bf16=False):
     dev = q.device
     if out is None:
         out = torch.empty((B * Lq, nhead * dh), dtype=torch.float32, device=dev)
+    nsplit = _mha_key_splits(B, Lq, Lk, nhead) if not (want_lse or bf16 or drop_p > 0) else 1
+    if nsplit > 1:
+        ws = torch.empty((lib.load().spot_mha_fwd_splitk_ws_floats(B, Lq, nhead, nsplit),), dtype=torch.float32, device=dev)
+        lib.call("spot_mha_fwd_splitk_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), out.stride(0), _p(kpm), _p(ws), nsplit,
+                 B, Lq, Lk, nhead, dh, 1.0 / math.sqrt(dh), _st())
+        return out, None
     lse = torch.empty((B, nhead, Lq), dtype=torch.float32, device=dev) if want_lse else None
     launch = lambda: lib.call("spot_mha_fwd_bf16" if bf16 else "spot_mha_fwd_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), out.stride(0), _p(lse),
                               _p(kpm), B, Lq, Lk, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), drop_seed, _st())
@@ -1403,7 +1450,7 @@ def _pos_table(pos2, W, b):
     return linear_fwd(pos2, W, b)
 
 
-class MHAFn(torch.autograd.Function):
+class MHAFn(_Fn):
     """z = xq + out_proj(MHA(q = xq + pos_q, k = xkv + pos_k, v = xkv))   (residual optional).
 
     nn.MultiheadAttention as the fusion layers use it (transt_fusion.py:145-149,
@@ -1438,7 +1485,7 @@ class MHAFn(torch.autograd.Function):
             kv = linear_fwd(xkv2, in_w[Cn:], in_b[Cn:], rowbias=tk)
             q, k, v = qkv, kv, kv[:, Cn:]
             ldq, ldk, ldv = Cn, 2 * Cn, 2 * Cn
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = _wants(ctx)
         sa = next_seed() if p_attn > 0 else 0
         so = next_seed() if p_out > 0 else 0
         attn, lse = mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, need_grad, drop_p=p_attn,

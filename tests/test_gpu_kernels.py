@@ -816,3 +816,28 @@ def test_conv3x3_with_folded_inference_batchnorm_and_kept_weights(ops, dil):
         assert not torch.equal(fresh, two_pass)
         ops.frozen_weights.clear()
 
+
+
+@pytest.mark.parametrize("Lq,Lk,nsplit", [(256, 256, 4), (1024, 1024, 8), (256, 1024, 5), (50, 77, 2), (50, 77, 8), (16, 64, 3)])
+def test_mha_forward_with_split_keys(ops, Lq, Lk, nsplit):
+    """The inference forward for small grids: key ranges handled by separate workgroups and merged; ragged sizes, a
+    padding mask that empties one whole range, more ranges than key tiles."""
+    from spot_amd import lib as L
+    B, nh, dh = 1, 4, 32
+    C = nh * dh
+    q, k, v = (det_input(n, (B, L_, C), 3, -2, 2) for n, L_ in (("q", Lq), ("k", Lk), ("v", Lk)))
+    kpm = np.zeros((B, Lk), bool)
+    kpm[0, :min(64, Lk - 1)] = True              # the first 64-key tile is masked out entirely
+    qg, kg, vg, kp = G(q).view(-1, C), G(k).view(-1, C), G(v).view(-1, C), G(kpm.astype(np.uint8))
+    ref = _ref_attn(T(q).double(), T(k).double(), T(v).double(), T(kpm), nh)
+    out = torch.empty((B * Lq, C), device=DEV)
+    ws = torch.empty((L.load().spot_mha_fwd_splitk_ws_floats(B, Lq, nh, nsplit),), device=DEV)
+    P = ops._p
+    L.call("spot_mha_fwd_splitk_f32", P(qg), C, P(kg), C, P(vg), C, P(out), C, P(kp), P(ws), nsplit, B, Lq, Lk, nh, dh,
+           1.0 / math.sqrt(dh), ops._st())
+    np.testing.assert_allclose(out.view(B, Lq, C).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+    one, _ = ops.mha_core_fwd(qg, C, kg, C, vg, C, B, Lq, Lk, nh, dh, kp, True)       # single-range kernel
+    np.testing.assert_allclose(out.cpu().numpy(), one.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    auto, lse = ops.mha_core_fwd(qg, C, kg, C, vg, C, B, Lq, Lk, nh, dh, kp, False)   # the wrapper's own choice
+    assert lse is None
+    np.testing.assert_allclose(auto.cpu().numpy(), one.cpu().numpy(), rtol=1e-5, atol=1e-6)
