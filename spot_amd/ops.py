@@ -949,6 +949,10 @@ def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, de
     stride, padding, dilation = one(stride), one(padding), one(dilation)
     if groups != 1 or None in (stride, padding, dilation):
         raise RuntimeError("spot_amd: deformable convolution supports groups = 1 and square stride / padding / dilation")
+    if x.shape[0] == 0:                 # an empty batch: nothing to launch
+        kh, kw = weight.shape[2:]
+        return x.new_empty((0, weight.shape[0], (x.shape[2] + 2 * padding - dilation * (kh - 1) - 1) // stride + 1,
+                            (x.shape[3] + 2 * padding - dilation * (kw - 1) - 1) // stride + 1))
     return DeformConvFn.apply(x, offset, weight, stride, padding, dilation, deformable_groups)
 
 
@@ -1031,7 +1035,8 @@ def conv_bn_act(x, conv, bn, relu=False):
     """[relu](bn(conv(x))) for any nn.Conv2d this library runs.  With `bn` in inference mode and no gradient wanted, a
     3x3 convolution on the any-size Winograd path takes the normalisation (and ReLU) in its output transform, and
     keeps its transformed weights inside `with frozen_weights():`; otherwise conv_general -> batch_norm_act."""
-    fold = (not bn.training and bn.track_running_stats and not torch.is_grad_enabled() and _winograd_general_applies(x, conv))
+    fold = (x.shape[0] > 0 and not bn.training and bn.track_running_stats and not torch.is_grad_enabled()
+            and _winograd_general_applies(x, conv))
     if not fold:
         return batch_norm_act(conv_general(x, conv), bn, relu=relu)
     x = _chk(x.contiguous())
@@ -1069,6 +1074,8 @@ def conv_general(x, conv):
     at least 16 channels on both sides, patch matrix + GEMM for the rest of what has one group, square stride and
     padding and zero padding mode, the module itself otherwise."""
     s, p, d = conv.stride, conv.padding, conv.dilation
+    if x.shape[0] == 0:                 # an empty batch: nothing to launch, the module shapes the empty result
+        return conv(x)
     if (OWN_CONV_IM2COL and x.is_cuda and conv.groups == 1 and s[0] == s[1] and isinstance(p, tuple) and p[0] == p[1]
             and conv.padding_mode == "zeros" and x.dtype == torch.float32):
         kh, kw = conv.kernel_size

@@ -73,3 +73,12 @@ def test_tracker_subwindow_on_device(ops):
         a = tr.get_subwindow(im, np.array(pos), S, sz, avg)
         b = tr.get_subwindow(torch.from_numpy(im).to(DEV), np.array(pos), S, sz, avg)
         assert np.array_equal(a.cpu().numpy(), want) and torch.equal(a, b)
+
+
+def test_crop_window_entirely_outside_the_frame_is_all_padding(ops):
+    im = det_input("frame4", (60, 80, 3), 2, 0, 256, np.uint8)
+    frame = torch.from_numpy(im).to(DEV)
+    for x0, y0 in ((-500, 10), (200, 10), (10, -300), (10, 90)):
+        for crop, S in ((64, 64), (100, 32), (33, 128)):
+            out = ops.crop_resize_u8(frame, x0, y0, crop, S, (7, 99, 201)).cpu().numpy()
+            assert (out[0, 0] == 7).all() and (out[0, 1] == 99).all() and (out[0, 2] == 201).all()

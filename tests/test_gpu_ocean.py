@@ -323,3 +323,17 @@ def test_winograd_any_size_matches_aten(ops, hw, pad, dil, bias, B):
         b = ops.ConvIm2colFn.apply(x.to(DEV), conv.weight, 1, padding[0], dil, conv.bias)
     assert torch.equal(a, y.detach())
     _close(a, b.cpu().numpy(), 3e-5, "two paths")
+
+
+def test_empty_batches(ops):
+    """Zero clips: convolution, deformable convolution and the label generator return empty results of the right
+    shape without launching anything."""
+    from spot_amd import ocean
+    conv = torch.nn.Conv2d(16, 16, 3, padding=1).to(DEV)
+    assert ops.conv_general(torch.empty(0, 16, 25, 25, device=DEV), conv).shape == (0, 16, 25, 25)
+    w = torch.randn(8, 16, 3, 3, device=DEV)
+    y = ops.deform_conv(torch.empty(0, 16, 9, 9, device=DEV), torch.empty(0, 18, 9, 9, device=DEV), w, 1, 1, 1, 1, 1)
+    assert y.shape == (0, 8, 9, 9)
+    gen = ocean.OceanLabelGenerator(_settings())
+    reg, reg_w = gen({"anno": torch.empty(0, 4, device=DEV)}, tag="reg")
+    assert reg.shape == (0, 25, 25, 4) and reg_w.shape == (0, 25, 25)
