@@ -253,8 +253,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     float db, dg;
     combine(partial, c, S, db, dg, red);
     if (s == 0 && threadIdx.x == 0) {
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
+        // atomic when accumulating: two passes through the same layer (template and search crops) may run their
+        // backward on two streams at once
+        if (dgamma) {
+            if (accumulate) atomicAdd(dgamma + c, dg);
+            else dgamma[c] = dg;
+        }
+        if (dbeta) {
+            if (accumulate) atomicAdd(dbeta + c, db);
+            else dbeta[c] = db;
+        }
     }
     const float mean = save_mean[c], rstd = save_rstd[c];
     const float M = (float)N * (float)(HWV * VW);

@@ -279,7 +279,11 @@ __global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __rest
         float o[3];
         gt6(tmp[a][0], tmp[a][1], tmp[a][2], tmp[a][3], tmp[a][4], tmp[a][5], o);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) wp[a * 3 + b] = accumulate ? wp[a * 3 + b] + o[b] : o[b];
+        for (int b = 0; b < 3; ++b) {
+            // atomic: the template and the search pass may deliver a shared weight's gradient from two streams at once
+            if (accumulate) atomicAdd(wp + a * 3 + b, o[b]);
+            else wp[a * 3 + b] = o[b];
+        }
     }
 }
 

@@ -515,7 +515,9 @@ _SPLITK_TARGET = int(os.environ.get("SPOT_SPLITK_TARGET", "512"))
 def _splitk_for(rows_out, cols_out, k):
     tiles = ((rows_out + 127) // 128) * ((cols_out + 127) // 128)
     want = max(1, _SPLITK_TARGET // tiles)
-    return max(1, min(want, k // 256 if k >= 256 else 1))
+    # never 1: with two or more ranges the kernel adds into the gradient with atomics, which is what makes it safe
+    # for the template and the search pass to deliver a shared weight's gradient from two streams at once
+    return max(2, min(want, k // 256 if k >= 256 else 1))
 
 
 def linear_wgrad(dy2, x2, out=None, accumulate=False, bias_out=None):
