@@ -849,17 +849,16 @@ class ConvIm2colFn(_Fn):
             dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=dev)
             lib.call("spot_col2im_f32", _p(dcols), _p(dx), B, Ci, H, W, kh, kw, stride, pad, dh, dw_, Kpad, Np, _st())
         if ctx.needs_input_grad[1]:
+            # only the first K rows of the patch matrix carry weights: the product is taken over those and added
+            # (split-K, atomically) straight into the gradient, padded or not
             sk = _sink(pw)
-            direct = sk is not None and Kpad == K
-            dwp = sk.view(Co, K) if direct else torch.zeros((Co, Kpad), dtype=torch.float32, device=dev)
-            gemm(dy, cols, dwp, Co, Kpad, B * Np, lda=Np, ldb=Np, ldc=Kpad, kseg=Np, segA=Co * Np, segB=Kpad * Np,
-                 splitk=_splitk_for(Co, Kpad, B * Np), accumulate=True)
+            dwk = sk.view(Co, K) if sk is not None else torch.zeros((Co, K), dtype=torch.float32, device=dev)
+            gemm(dy, cols, dwk, Co, K, B * Np, lda=Np, ldb=Np, ldc=K, kseg=Np, segA=Co * Np, segB=Kpad * Np,
+                 splitk=_splitk_for(Co, K, B * Np), accumulate=True)
             if sk is not None:
-                if not direct:
-                    sk.view(Co, K).add_(dwp[:, :K])
                 _sink_done(pw)
             else:
-                dw = dwp[:, :K].reshape(weight.shape)
+                dw = dwk.reshape(weight.shape)
         return dx, dw, None, None, None, dbias
 
 
@@ -931,17 +930,16 @@ class DeformConvFn(_Fn):
             lib.call("spot_deform_col2im_f32", _p(dcols), _p(x), _p(offset), _p(dx), _p(doff), _p(ws), B, Ci, H, W, kh, kw,
                      stride, pad, dil, dgroups, Kpad, Np, _st())
         if ctx.needs_input_grad[2]:
+            # only the first K rows of the patch matrix carry weights: the product is taken over those and added
+            # (split-K, atomically) straight into the gradient, padded or not
             sk = _sink(pw)
-            direct = sk is not None and Kpad == K
-            dwp = sk.view(Co, K) if direct else torch.zeros((Co, Kpad), dtype=torch.float32, device=dev)
-            gemm(dy, cols, dwp, Co, Kpad, B * Np, lda=Np, ldb=Np, ldc=Kpad, kseg=Np, segA=Co * Np, segB=Kpad * Np,
-                 splitk=_splitk_for(Co, Kpad, B * Np), accumulate=True)
+            dwk = sk.view(Co, K) if sk is not None else torch.zeros((Co, K), dtype=torch.float32, device=dev)
+            gemm(dy, cols, dwk, Co, K, B * Np, lda=Np, ldb=Np, ldc=K, kseg=Np, segA=Co * Np, segB=Kpad * Np,
+                 splitk=_splitk_for(Co, K, B * Np), accumulate=True)
             if sk is not None:
-                if not direct:
-                    sk.view(Co, K).add_(dwp[:, :K])
                 _sink_done(pw)
             else:
-                dw = dwp[:, :K].reshape(weight.shape)
+                dw = dwk.reshape(weight.shape)
         return dx, doff, dw, None, None, None, None
 
 
