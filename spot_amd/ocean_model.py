@@ -166,6 +166,34 @@ class Ocean(nn.Module):
                                     self.search_size, iou_prediction=False)
         return out["pred_logits"], out["pred_boxes"], out["align_logits"]
 
+    def _branch(self, img, crop):
+        _, f = self.feature_extractor(img)
+        if self.neck is None:
+            return f
+        return self.neck(f, crop=True)[1] if crop else self.neck(f, crop=False)
+
+    def _features_pair(self, template, search):
+        """Backbone + neck of the template and the search crops (the reference runs them back to back, template
+        first, ocean_model.py:414-419).  The template pass works on 63x63 ... 15x15 maps that cannot fill the chip, so
+        on a GPU it runs on a second stream beside the search pass; the search pass leaves its BatchNorm
+        running-statistics updates pending and they are applied after the join, which keeps the reference's order
+        (template's update first)."""
+        from . import fusion
+        if not (fusion.TWO_STREAMS and search.is_cuda):
+            return self._branch(template, True), self._branch(search, False)
+        main = torch.cuda.current_stream()
+        side = fusion.side_stream(search.device)
+        ops.register_side_stream(side, main)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            zf = self._branch(template, True)
+        with ops.defer_running_stats() as pending:
+            xf = self._branch(search, False)
+        main.wait_stream(side)
+        zf.record_stream(main)
+        pending.apply()
+        return zf, xf
+
     def _fusion_pipeline(self, xf, zf, pred_to_img_tag=False, b_iou=0):
         return ocean.fusion_pipeline(self.connect_model, self.align_head, xf, zf, self.grid_x, self.grid_y, self.search_size,
                                      iou_prediction=self.iou_prediction, b_iou=b_iou, pred_to_img_tag=pred_to_img_tag)
@@ -209,11 +237,7 @@ class Ocean(nn.Module):
                 templates.append(data[t + "_images"])
         template = (templates[0] if len(templates) == 1 else torch.cat(templates, dim=0)).detach()
         search = (searches[0] if len(searches) == 1 else torch.cat(searches, dim=0)).detach()
-        _, zf = self.feature_extractor(template)
-        _, xf = self.feature_extractor(search)
-        if self.neck is not None:
-            _, zf = self.neck(zf, crop=True)
-            xf = self.neck(xf, crop=False)
+        zf, xf = self._features_pair(template, search)
         if teacher_data is not None:
             out = self._fusion_pipeline(xf, zf, pred_to_img_tag=True, b_iou=self._get_batch_size(teacher_data))
         else:

@@ -271,3 +271,35 @@ def test_ocean_trainer_iteration_end_to_end():
         assert stats is not None and torch.isfinite(stats["Loss/total"])
     assert not torch.equal(w0, student.connect_model.bbox_pred.weight.detach())
     assert not torch.equal(t0, next(teacher.parameters()).detach())          # iteration 1 began with an EMA update
+
+
+def test_ocean_two_stream_features_match_sequential():
+    """Template pass on a second stream beside the search pass (the search pass's running-statistics updates applied
+    after the join): same outputs, same BatchNorm running buffers and same gradients as one stream."""
+    from spot_amd import fusion, ocean
+    from spot_amd.ocean_model import OceanSparseActor, ocean_resnet50
+    S = _settings()
+    crit = ocean.ocean_loss(S)
+    sup, sp = _pair("template", "search", 2, 21), _pair("relay", "aug", 3, 22)
+    sup["masks"] = torch.zeros(2, dtype=torch.bool, device=DEV)
+    sp["masks"] = torch.ones(3, dtype=torch.bool, device=DEV)
+    saved, runs = fusion.TWO_STREAMS, []
+    try:
+        for two in (False, True):
+            fusion.TWO_STREAMS = two
+            student = det_fill_positive_norm_(ocean_resnet50(_settings(device="cpu"), "student"), 5).to(DEV).train()
+            actor = OceanSparseActor(S, student, student, crit)
+            loss, _ = actor(mode="spsup", burnin_data=TensorDict(dict(sup)), sp_data=TensorDict(dict(sp)))
+            loss.backward()
+            torch.cuda.synchronize()
+            runs.append((loss.detach().clone(), {n: p.grad.clone() for n, p in student.named_parameters() if p.grad is not None},
+                         {n: b.clone() for n, b in student.named_buffers() if "running" in n or "tracked" in n}))
+    finally:
+        fusion.TWO_STREAMS = saved
+    (l0, g0, b0), (l1, g1, b1) = runs
+    assert torch.equal(l0, l1)
+    for n in b0:
+        assert torch.equal(b0[n], b1[n]), n
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for n in g0:          # weight gradients are summed by float atomics (split-K): the order of the addends varies
+        assert float((g0[n] - g1[n]).abs().max()) <= 5e-5 * float(g0[n].abs().max()) + 1e-6 * gmax, n
