@@ -1441,8 +1441,19 @@ class frozen_weights:
     def forget(module):
         """Drop the entries derived from this module's parameters (after its weights changed) and leave those of
         other networks, whose captured graphs may still read them."""
-        ptrs = {p.data_ptr() for p in module.parameters()}
-        for key in [k for k in frozen_weights._tables if any(isinstance(e, int) and e in ptrs for e in k)]:
+        import bisect
+        spans = sorted((p.data_ptr(), p.data_ptr() + p.numel() * p.element_size()) for p in module.parameters())
+        starts = [a for a, _ in spans]
+
+        def inside(addr):                # keys hold addresses of parameters or of slices of them
+            i = bisect.bisect_right(starts, addr) - 1
+            return i >= 0 and addr < spans[i][1]
+        ids = {id(p) for p in module.parameters()}
+
+        def derived(value):              # entries keep their operands: a parameter itself or a view of one
+            return any(torch.is_tensor(t) and (id(t) in ids or (t._base is not None and id(t._base) in ids)) for t in value)
+        for key in [k for k, v in frozen_weights._tables.items()
+                    if derived(v) or any(isinstance(e, int) and e > 4096 and inside(e) for e in k)]:
             del frozen_weights._tables[key]
 
 

@@ -303,3 +303,31 @@ def test_ocean_two_stream_features_match_sequential():
     gmax = max(float(g.abs().max()) for g in g0.values())
     for n in g0:          # weight gradients are summed by float atomics (split-K): the order of the addends varies
         assert float((g0[n] - g1[n]).abs().max()) <= 5e-5 * float(g0[n].abs().max()) + 1e-6 * gmax, n
+
+
+def test_frozen_weight_tables_are_forgotten_per_network():
+    """Tables derived from a network's weights go when that network says its weights changed, also after its
+    parameters moved into flat storage; another network's tables stay (a captured graph may still read them)."""
+    from spot_amd import ops
+    from spot_amd.arena import ParamArena
+    a = torch.nn.Conv2d(32, 32, 3, padding=1, bias=False).to(DEV)
+    b = torch.nn.Conv2d(32, 32, 3, padding=1, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(32).to(DEV).eval()
+    x = torch.randn(2, 32, 15, 15, device=DEV)
+    ops.frozen_weights.clear()
+    with torch.no_grad(), ops.frozen_weights():
+        ya = ops.conv_bn_act(x, a, bn, relu=True)
+        ops.conv_bn_act(x, b, bn, relu=True)
+    assert len(ops.frozen_weights._tables) == 2
+    ParamArena(a)                                    # the parameter's storage moves
+    ops.frozen_weights.forget(a)
+    assert len(ops.frozen_weights._tables) == 1
+    with torch.no_grad():
+        a.weight.mul_(2.0)
+    with torch.no_grad(), ops.frozen_weights():
+        ya2 = ops.conv_bn_act(x, a, bn, relu=False)
+        ref = ops.batch_norm_act(ops.conv_general(x, a), bn)
+    np.testing.assert_allclose(ya2.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=1e-5 * float(ref.abs().max()))
+    ops.frozen_weights.forget(b)
+    ops.frozen_weights.forget(a)
+    assert len(ops.frozen_weights._tables) == 0 and ya.shape == ya2.shape
