@@ -167,6 +167,9 @@ class TransT_Tracker(object):
         self.window = np.outer(hanning, hanning).flatten()
         self._window_dev = torch.from_numpy(self.window).cuda()
         self.initialize_features()
+        inner = self.net.__dict__.get("net", self.net) if hasattr(self.net, "__dict__") else self.net
+        if isinstance(inner, torch.nn.Module):
+            ops.frozen_weights.forget(inner)        # the network may have been trained since the last sequence
         bbox = info["init_bbox"]
         self.center_pos = np.array([bbox[0] + bbox[2] / 2, bbox[1] + bbox[3] / 2])
         self.size = np.array([bbox[2], bbox[3]])
