@@ -209,7 +209,9 @@ class TransT_Tracker(object):
             from . import fusion
             two = fusion.TWO_STREAMS
             try:
-                fusion.TWO_STREAMS = False                      # one stream inside the captured graph
+                # the template stream of the fusion layers forks from and rejoins the capture stream, so the replayed
+                # graph keeps the two branches concurrent (SPOT_GRAPH_TWO_STREAMS=0: one stream inside the graph)
+                fusion.TWO_STREAMS = two and os.environ.get("SPOT_GRAPH_TWO_STREAMS", "1") == "1"
                 self._x_static = x_crop.clone()
                 # one eager pass on the capture stream first: library handles and code objects that are created
                 # per stream on first use must exist before capture begins
