@@ -110,15 +110,35 @@ class box_tower(nn.Module):
             self.add_module("iou_pred_tower", tower())
             self.iou_pred = nn.Conv2d(outchannels, 1, kernel_size=3, stride=1, padding=1)
 
-    def forward(self, search, kernel, iou_prediction=True, batch_iou=0):
+    def _cls_branch(self, search, kernel):
         cls_z, cls_x = self.cls_encode(kernel, search)
-        reg_z, reg_x = self.reg_encode(kernel, search)
         cls_dw = self.cls_dw(cls_z, cls_x)
+        c = _conv_bn_relu(self.cls_tower, cls_dw)
+        return 0.1 * ops.conv_general(c, self.cls_pred), cls_dw
+
+    def forward(self, search, kernel, iou_prediction=True, batch_iou=0):
+        # The classification and the regression branch share nothing but their inputs (own encoders, correlation
+        # weights, towers, BatchNorm layers): on a GPU the classification branch runs on a second stream beside
+        # the regression branch, whose 25x25 ... 45x45 maps alone do not fill the chip at small batches.
+        from . import fusion
+        two = fusion.TWO_STREAMS and search.is_cuda
+        if two:
+            main = torch.cuda.current_stream()
+            side = fusion.side_stream(search.device)
+            ops.register_side_stream(side, main)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                cls, cls_dw = self._cls_branch(search, kernel)
+        reg_z, reg_x = self.reg_encode(kernel, search)
         reg_dw = self.reg_dw(reg_z, reg_x)
         x_reg = _conv_bn_relu(self.bbox_tower, reg_dw)
         x = torch.exp(torch.clamp_max(self.adjust * ops.conv_general(x_reg, self.bbox_pred) + self.bias, max=4.7))
-        c = _conv_bn_relu(self.cls_tower, cls_dw)
-        cls = 0.1 * ops.conv_general(c, self.cls_pred)
+        if two:
+            main.wait_stream(side)
+            cls.record_stream(main)
+            cls_dw.record_stream(main)
+        else:
+            cls, cls_dw = self._cls_branch(search, kernel)
         extra = TensorDict()
         if self.iou_prediction and iou_prediction and batch_iou > 0:
             t = _conv_bn_relu(self.iou_pred_tower, reg_dw.detach()[:batch_iou])
