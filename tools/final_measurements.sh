@@ -31,4 +31,9 @@ echo microbench done
 timeout -k 10 400 python3 tools/measure_configs.py > $O/configs.log 2>&1 || exit 1
 timeout -k 10 300 python3 bench.py --attention bf16 --clips 48 --sup 16 --no-cpu-baseline > $O/bench_cfg4.log 2>&1 || exit 1
 grep "^{" $O/configs.log | cut -c1-200
+# the Siamese variant: head at both search sizes, then tracker rate and one training iteration
+timeout -k 10 300 python3 tools/ocean_bench.py --batch 32 --search 255 > $O/ocean.log 2>&1 || exit 1
+timeout -k 10 400 python3 tools/ocean_bench.py --batch 128 --search 384 --steps 3 >> $O/ocean.log 2>&1 || exit 1
+timeout -k 10 300 python3 tools/ocean_bench.py variant 8 >> $O/ocean.log 2>&1 || exit 1
+grep "^{" $O/ocean.log | cut -c1-160
 echo all done
