@@ -245,6 +245,40 @@ def test_deform_conv_matches_oracle(ops, hw, C, Co, dg):
     assert float(og.grad[0, :, 0, 0].abs().max()) == 0.0          # invalid samples carry no gradient
 
 
+def test_deform_conv_reduces_to_ordinary_convolution_at_head_size(ops):
+    """Size-independent anchors of the deformable convolution at the aligned head's size (256 channels, 25 x 25,
+    32 clips), against aten's convolution on the same device: zero offsets; one tap moved by whole pixels (rows on
+    offset channel 2k, columns on 2k+1, ltr/models/neck/dcn/src/deform_conv_cuda_kernel.cu:220-227); half a pixel on
+    every tap = the mean of two translations; with zero offsets the input and weight gradients are aten's."""
+    from tests.test_oracle_golden import _conv3x3_of_translated
+    B, C, Co, S = 32, 256, 256, 25
+    x = G(det_input("x", (B, C, S, S), 41, -1, 1))
+    w = G(det_input("w", (Co, C, 3, 3), 42, -0.05, 0.05))
+    zero = torch.zeros(B, 18, S, S, device=DEV)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    _close(ops.deform_conv(x, zero, w, 1, 1, 1, 1, 1), ref.cpu().numpy(), 3e-6, "zero offsets")
+    tap, dy, dx = 5, -2, 1
+    off = zero.clone()
+    off[:, 2 * tap], off[:, 2 * tap + 1] = dy, dx
+    w_rest, w_tap = w.double().clone(), torch.zeros_like(w, dtype=torch.float64)
+    w_rest[:, :, 1, 2] = 0
+    w_tap[:, :, 1, 2] = w[:, :, 1, 2].double()
+    want = F.conv2d(x.double(), w_rest, None, 1, 1) + _conv3x3_of_translated(x.double(), w_tap, dy, dx)
+    _close(ops.deform_conv(x, off, w, 1, 1, 1, 1, 1), want.cpu().numpy(), 3e-6, "one tap moved")
+    off = zero.clone()
+    off[:, 1::2] = 0.5
+    want = 0.5 * (ref + _conv3x3_of_translated(x.double(), w.double(), 0, 1))
+    _close(ops.deform_conv(x, off, w, 1, 1, 1, 1, 1), want.cpu().numpy(), 3e-6, "half a pixel")
+    # gradients: with zero offsets the input and weight gradients are aten's
+    up = G(det_input("up", (B, Co, S, S), 43, -1, 1))
+    xg, wg, og = x.clone().requires_grad_(), w.clone().requires_grad_(), zero.clone().requires_grad_()
+    (ops.deform_conv(xg, og, wg, 1, 1, 1, 1, 1) * up).sum().backward()
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    (F.conv2d(xr, wr, None, 1, 1) * up.double()).sum().backward()
+    _close(xg.grad, xr.grad.cpu().numpy(), 3e-6, "dx")
+    _close(wg.grad, wr.grad.cpu().numpy(), 3e-6, "dw")
+
+
 def test_align_head_and_fusion_pipeline(ops, golden):
     """The aligned head on the golden tower outputs: zero offsets make the deformable convolution an ordinary 3x3
     convolution; the whole pipeline (tower, box decoding, offsets, aligned head) equals the oracle's composition and

@@ -422,3 +422,63 @@ def test_g20_ocean_tracker_update(golden):
         iy, ix = (ys >= 0) & (ys < 120), (xs >= 0) & (xs < 160)
         pad[np.ix_(iy, ix)] = im[np.ix_(ys[iy], xs[ix])]
         assert np.array_equal(pad.transpose(2, 0, 1), g["sub%d" % i]), i
+
+
+def _conv3x3_of_translated(x, w, dy, dx):
+    """3x3 / pad 1 convolution that reads x[h + dy, w + dx] where it would read x[h, w], the map continued by zeros
+    (the translation is applied to the zero-extended plane, so rows that move in from the border are kept)."""
+    import torch.nn.functional as F
+    P = max(abs(dy), abs(dx)) + 1
+    H, W = x.shape[-2:]
+    xp = F.pad(x, (P, P, P, P))
+    moved = torch.zeros_like(xp)
+    Hp, Wp = xp.shape[-2:]
+    hs, he = max(0, -dy), min(Hp, Hp - dy)
+    ws, we = max(0, -dx), min(Wp, Wp - dx)
+    moved[..., hs:he, ws:we] = xp[..., hs + dy:he + dy, ws + dx:we + dx]
+    return F.conv2d(moved, w)[..., P - 1:P - 1 + H, P - 1:P - 1 + W]
+
+
+def test_deform_conv_restatement_reduces_to_ordinary_convolution():
+    """The deformable-convolution restatement has no fixture of the reference behind it, so it is anchored to the
+    operator's defining properties (ltr/models/neck/dcn/src/deform_conv_cuda_kernel.cu:220-227: channel 2k of the
+    offsets moves tap k along rows, 2k+1 along columns; a sample is zero unless -1 < h < H and -1 < w < W):
+    zero offsets give aten's convolution; whole-pixel offsets of one tap give that tap's weight on the translated,
+    zero-extended map; a half-pixel offset gives the mean of the two neighbouring translations; deformable groups move
+    only their own channels."""
+    import torch.nn.functional as F
+    B, C, Co, H, W = 2, 6, 5, 9, 11
+    x = T(det_input("x", (B, C, H, W), 31, -1, 1)).double()
+    w = T(det_input("w", (Co, C, 3, 3), 32, -0.5, 0.5)).double()
+    zero = torch.zeros(B, 18, H, W, dtype=torch.float64)
+    ref = F.conv2d(x, w, None, 1, 1)
+    torch.testing.assert_close(O.deform_conv(x, zero, w, 1, 1, 1), ref, rtol=1e-12, atol=1e-12)
+    # strided, dilated, unpadded forms
+    for stride, pad, dil in ((2, 1, 1), (1, 2, 2), (1, 0, 1)):
+        r = F.conv2d(x, w, None, stride, pad, dil)
+        z = torch.zeros(B, 18, r.shape[2], r.shape[3], dtype=torch.float64)
+        torch.testing.assert_close(O.deform_conv(x, z, w, stride, pad, dil), r, rtol=1e-12, atol=1e-12)
+    # one tap moved by whole pixels: rows on channel 2k, columns on channel 2k + 1
+    for tap, (dy, dx) in ((0, (2, 0)), (4, (0, -3)), (7, (-1, 2))):
+        off = zero.clone()
+        off[:, 2 * tap], off[:, 2 * tap + 1] = dy, dx
+        ky, kx = divmod(tap, 3)
+        w_rest = w.clone()
+        w_rest[:, :, ky, kx] = 0
+        w_tap = torch.zeros_like(w)
+        w_tap[:, :, ky, kx] = w[:, :, ky, kx]
+        want = F.conv2d(x, w_rest, None, 1, 1) + _conv3x3_of_translated(x, w_tap, dy, dx)
+        torch.testing.assert_close(O.deform_conv(x, off, w, 1, 1, 1), want, rtol=1e-12, atol=1e-12)
+    # half a pixel down on every tap: the mean of the map and its translation by one row
+    off = zero.clone()
+    off[:, 0::2] = 0.5
+    want = 0.5 * (ref + _conv3x3_of_translated(x, w, 1, 0))
+    torch.testing.assert_close(O.deform_conv(x, off, w, 1, 1, 1), want, rtol=1e-12, atol=1e-12)
+    # two deformable groups: the second group's offsets leave the first half of the channels alone
+    off2 = torch.zeros(B, 36, H, W, dtype=torch.float64)
+    off2[:, 18 + 1::2] = 1.0                                        # second group, one column to the right
+    w_lo, w_hi = w.clone(), w.clone()
+    w_lo[:, C // 2:] = 0
+    w_hi[:, :C // 2] = 0
+    want = F.conv2d(x, w_lo, None, 1, 1) + _conv3x3_of_translated(x, w_hi, 0, 1)
+    torch.testing.assert_close(O.deform_conv(x, off2, w, 1, 1, 1, 2), want, rtol=1e-12, atol=1e-12)
