@@ -303,7 +303,19 @@ int spot_mha_fwd_splitk_f32(const float* q, long ldq, const float* k, long ldk, 
                             long ldo, const unsigned char* key_padding_mask, float* ws, int nsplit, int B, int Lq, int Lk,
                             int nhead, int head_dim, float scale, hipStream_t stream);
 
-/* Gradient of the above w.r.t. q, k, v given d_out.  delta_ws: workspace [B,nhead,Lq] floats.
+/* spot_mha_fwd_splitk_f32 without the workspace argument, for callers that cannot allocate device memory: a frame
+ * replayed under HIP graph capture, a serving loop or a harness that forbids hipMalloc.  It has no counterpart in the
+ * reference.  The partial sums go to a static device array of SPOT_MHA_SPLITK_NOALLOC_MAX_FLOATS floats (8.5 MiB,
+ * held by every GPU the library runs on until the process ends); a call needing more, i.e.
+ * spot_mha_fwd_splitk_ws_floats(B, Lq, nhead, nsplit) > SPOT_MHA_SPLITK_NOALLOC_MAX_FLOATS, is rejected.  The call
+ * makes no hipMalloc / hipFree.  Same results as spot_mha_fwd_splitk_f32 bit for bit.  Calls that overlap on one GPU
+ * (two streams, two threads) share the array and race: serialise them. */
+#define SPOT_MHA_SPLITK_NOALLOC_MAX_FLOATS 2228224L   /* 8 key ranges x 8 heads x 1024 queries x (32 + 2) */
+int spot_mha_fwd_splitk_noalloc_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                                    float* out, long ldo, const unsigned char* key_padding_mask, int nsplit, int B,
+                                    int Lq, int Lk, int nhead, int head_dim, float scale, hipStream_t stream);
+
+/* Gradient of spot_mha_fwd_f32 w.r.t. q, k, v given d_out.  delta_ws: workspace [B,nhead,Lq] floats.
  * dq is accumulated with atomic adds and is cleared by this call. */
 int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                      const float* out, long ldo, const float* d_out, long lddo, const float* lse,

@@ -17,6 +17,8 @@
 // With queries on the lanes the online-softmax state (running max, sum, rescale
 // factor) is one scalar per lane and the row reductions are 15 in-register ops
 // plus one exchange with lane^32.
+#include <mutex>
+
 #include "common.h"
 #include "../../include/spot_hip.h"
 
@@ -805,4 +807,60 @@ extern "C" int spot_mha_fwd_splitk_f32(const float* q, long ldq, const float* k,
     mha_merge_kernel<<<spot_ceil_div(total, 256), 256, 0, stream>>>(part_o, part_ml, out, ldo, B, Lq, nhead, nsplit);
     SPOT_CHECK_LAUNCH("mha_fwd_splitk(merge)");
     return SPOT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The split-key forward for callers that may not allocate (a frame replayed under HIP graph capture, serving loops
+// that forbid hipMalloc): the partial sums live in a file-scope device array instead of a caller workspace.
+// Every GPU the library runs on holds its own copy of the array until the process ends; its address on a device is
+// resolved once, with that device current, on the entry point's first call there.  Every (range, clip, head, query)
+// slot the merge kernel reads is written by the forward kernel of the same call (an empty key range stores max = -inf,
+// sum = 0), so nothing has to be cleared between calls; calls that overlap on one GPU share the array and race.
+// ---------------------------------------------------------------------------
+static_assert(SPOT_MHA_SPLITK_NOALLOC_MAX_FLOATS == 8L * 8 * 1024 * (DH + 2), "8 key ranges x 8 heads x 1024 queries");
+#define SPOT_SPLITK_SCRATCH_FLOATS SPOT_MHA_SPLITK_NOALLOC_MAX_FLOATS
+static __device__ __align__(256) float scratch[SPOT_SPLITK_SCRATCH_FLOATS];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+float* g_scratch_ptr[MAX_DEVICES] = {};
+
+// Device address of `scratch` on the current device (nullptr + error text on failure).
+float* scratch_on_current_device() {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+        spot_set_error("mha_fwd_splitk_noalloc: hipGetDevice failed or device %d beyond %d: %s", dev, MAX_DEVICES,
+                       hipGetErrorString(e));
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            spot_set_error("mha_fwd_splitk_noalloc: hipGetSymbolAddress(scratch) failed on device %d: %s", dev,
+                           hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    return g_scratch_ptr[dev];
+}
+}  // namespace
+
+extern "C" int spot_mha_fwd_splitk_noalloc_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                                               float* out, long ldo, const unsigned char* key_padding_mask, int nsplit,
+                                               int B, int Lq, int Lk, int nhead, int head_dim, float scale,
+                                               hipStream_t stream) {
+    const long need = spot_mha_fwd_splitk_ws_floats(B, Lq, nhead, nsplit);
+    SPOT_CHECK_ARG(need <= SPOT_SPLITK_SCRATCH_FLOATS,
+                   "mha_fwd_splitk_noalloc: nsplit*B*Lq*heads*(head_dim+2) = %ld floats exceeds the static scratch of %ld "
+                   "floats (nsplit=%d B=%d Lq=%d heads=%d); use spot_mha_fwd_splitk_f32 with a caller workspace",
+                   need, (long)SPOT_SPLITK_SCRATCH_FLOATS, nsplit, B, Lq, nhead);
+    float* ws = scratch_on_current_device();
+    if (!ws) return SPOT_ERR_LAUNCH;
+    return spot_mha_fwd_splitk_f32(q, ldq, k, ldk, v, ldv, out, ldo, key_padding_mask, ws, nsplit, B, Lq, Lk, nhead,
+                                   head_dim, scale, stream);
 }

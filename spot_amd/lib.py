@@ -94,6 +94,7 @@ SIGNATURES = {
     "spot_conv3x3_winograd_wgrad_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
     "spot_mha_fwd_splitk_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp] + [i32] * 6 + [f32, vp],
+    "spot_mha_fwd_splitk_noalloc_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp] + [i32] * 6 + [f32, vp],
     "spot_mha_bwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64,
                          i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
     "spot_mha_fwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
