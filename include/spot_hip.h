@@ -40,6 +40,13 @@ const char* spot_last_error(void);
 int spot_preprocess_u8_f32(const unsigned char* images, const float* scale, const float* mean3,
                            const float* std3, float* out, int B, int C, int H, int W, hipStream_t stream);
 
+/* PositionEmbeddingSine.forward (normalize = True), ltr/models/neck/position_encoding.py:27-45.  mask [B,H,W]
+ * bytes (non-zero = padded cell) or NULL for no padding; out [B, H*W, 2*num_pos_feats] token rows: num_pos_feats
+ * features of the row coordinate, then as many of the column coordinate (the reference's [B, 2F, H, W] map is the
+ * transpose of each clip's rows).  H*W <= 4096. */
+int spot_posenc_sine_f32(const unsigned char* mask, float* out, int B, int H, int W, int num_pos_feats,
+                         float temperature, float scale, hipStream_t stream);
+
 /* ---- pseudo-label path -------------------------------------------------- */
 
 /* TranstSparseActor._decode_teacher_result, ltr/actor/transt_sparse_actor.py:57-98.
@@ -89,10 +96,12 @@ int spot_tracker_decode(const float* pred_logits, const float* pred_boxes, const
                         double window_penalty, double* best6, double* pscore_map, int B, int L,
                         hipStream_t stream);
 
-/* TrackingMatcher.forward, ltr/models/loss/transt_matcher.py:24-109, as dense masks: pos_mask[b,t] = 1 for
+/* TrackingMatcher.forward, ltr/models/loss/transt_matcher.py:24-109, as dense maps: pos_mask[b,t] = 1 for
  * tokens whose cell lies in the ground-truth box gt_cxcywh[b] (normalised cx,cy,w,h; float64 ceil arithmetic
- * as the reference's Python floats), neg_mask[b,t] = 1 for the ring of width gap around it (NULL to skip:
- * the reference builds negatives for the supervised tag only).  Masks are [B, feat_sz*feat_sz] bytes. */
+ * as the reference's Python floats; cell ranges cut the grid the way its numpy slices do, negative bounds counting
+ * from the end), neg_mask[b,t] = how many of the four rectangles of the ring of width gap around it (:92-95) hold
+ * the token: 0 or 1 for a box on the map, up to 4 once a bound has wrapped (NULL to skip: the reference builds
+ * negatives for the supervised tag only).  Both are [B, feat_sz*feat_sz] bytes. */
 int spot_match_masks(const float* gt_cxcywh, int B, int feat_sz, int gap, unsigned char* pos_mask,
                      unsigned char* neg_mask, hipStream_t stream);
 

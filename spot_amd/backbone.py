@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import ops
+from . import lib, ops
 from .tensordict import NestedTensor
 
 
@@ -98,49 +98,43 @@ class ResNet50Layer3(nn.Module):
 
 
 class PositionEmbeddingSine(nn.Module):
-    """ltr/models/neck/position_encoding.py:11-45 (normalize=True, scale 2*pi, T=10000).
+    """ltr/models/neck/position_encoding.py:11-45 (normalize=True, scale 2*pi, T=10000), one kernel
+    (spot_posenc_sine_f32) that writes token rows.
 
-    For the all-False masks of full-size crops the encoding is a constant of
-    (H, W): it is computed once on the host and cached per device as token rows
-    [H*W, 2*num_pos_feats].  Masked inputs take the general on-device path.
+    For the all-False masks of full-size crops the encoding is a constant of (H, W): it is computed once per
+    device and kept as [H*W, 2*num_pos_feats] rows.  Masked inputs are encoded per call.
     """
 
     def __init__(self, num_pos_feats=64, temperature=10000, normalize=True, scale=None):
         super().__init__()
+        if not normalize:
+            raise RuntimeError("spot_amd: PositionEmbeddingSine is built for normalize=True (the reference's setting)")
         self.num_pos_feats = num_pos_feats
         self.temperature = temperature
         self.normalize = normalize
         self.scale = 2 * math.pi if scale is None else scale
         self._cache = {}
 
+    def _rows(self, mask, B, H, W, device):
+        out = torch.empty((B, H * W, 2 * self.num_pos_feats), dtype=torch.float32, device=device)
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        lib.call("spot_posenc_sine_f32", ops._p(m), ops._p(out), B, H, W, self.num_pos_feats, float(self.temperature),
+                 float(self.scale), ops._st())
+        return out
+
     def rows(self, H, W, device):
-        """Encoding of an unmasked H x W map as [H*W, C] rows (float32 arithmetic as the reference)."""
+        """Encoding of an unmasked H x W map as [H*W, C] rows."""
         key = (H, W, str(device))
         if key not in self._cache:
-            mask = torch.zeros(1, H, W, dtype=torch.bool)
-            pos = self._encode(mask)                       # [1, C, H, W] on CPU
-            self._cache[key] = pos[0].flatten(1).t().contiguous().to(device)
+            self._cache[key] = self._rows(None, 1, H, W, device)[0]
         return self._cache[key]
 
-    def _encode(self, mask):
-        not_mask = (~mask).to(torch.float32)
-        y_embed = not_mask.cumsum(1)
-        x_embed = not_mask.cumsum(2)
-        if self.normalize:
-            eps = 1e-6
-            y_embed = y_embed / (y_embed[:, -1:, :] + eps) * self.scale
-            x_embed = x_embed / (x_embed[:, :, -1:] + eps) * self.scale
-        dim_t = torch.arange(self.num_pos_feats, dtype=torch.float32, device=mask.device)
-        dim_t = self.temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / self.num_pos_feats)
-        pos_x = x_embed[:, :, :, None] / dim_t
-        pos_y = y_embed[:, :, :, None] / dim_t
-        pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
-        pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
-        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
-
     def forward(self, tensor_list: NestedTensor):
-        assert tensor_list.mask is not None
-        return self._encode(tensor_list.mask)
+        """[B, C, H, W] as the reference returns it."""
+        mask = tensor_list.mask
+        assert mask is not None
+        B, H, W = mask.shape
+        return self._rows(mask, B, H, W, mask.device).view(B, H, W, -1).permute(0, 3, 1, 2)
 
 
 class BackboneBase(nn.Module):

@@ -18,7 +18,8 @@ from . import lib, ops
 
 
 class TrackingMatcher(nn.Module):
-    """Returns dense masks instead of index lists: (pos [B,L] bool, neg [B,L] bool or None)."""
+    """Returns dense maps instead of index lists: (pos [B,L] bool, neg [B,L] uint8 multiplicity or None); a negative
+    token listed k times by the reference (possible only for boxes off the map) has neg = k."""
 
     @torch.no_grad()
     def forward(self, outputs, targets, tag="sup"):
@@ -30,7 +31,7 @@ class TrackingMatcher(nn.Module):
         pos = torch.empty((bs, num_queries), dtype=torch.uint8, device=logits.device)
         neg = torch.empty_like(pos) if tag == "sup" else None
         lib.call("spot_match_masks", ops._p(gt), bs, n, 3, ops._p(pos), ops._p(neg), ops._st())
-        return pos.bool(), (neg.bool() if neg is not None else None)
+        return pos.bool(), neg
 
 
 def build_matcher():
@@ -79,7 +80,7 @@ class SetCriterionTransT(nn.Module):
             num_neg = neg.sum().clamp(min=1).float()
             err = (pred - iou.detach()).abs()
             losses["loss_iou_pred"] = torch.where(pos, err, zero).sum() / num_pos + \
-                torch.where(neg, err, zero).sum() / num_neg
+                torch.where(neg > 0, err * neg, zero).sum() / num_neg
         return losses
 
 

@@ -361,3 +361,55 @@ extern "C" int spot_adamw_f32(float* params, const float* grads, float* exp_avg,
     SPOT_CHECK_LAUNCH("adamw");
     return SPOT_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Sine position encoding (ltr/models/neck/position_encoding.py:27-45, normalize = True): per clip, the running count
+// of unmasked cells down each column (y) and along each row (x), divided by the column's / row's last count + 1e-6
+// and scaled; feature c of an axis is sin (c even) or cos (c odd) of that value / temperature^(2 floor(c/2) / F).
+// Output as token rows [B, H*W, 2F]: F features of y then F of x.  One workgroup per clip; the two count maps live
+// in LDS.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int POSENC_MAX_CELLS = 4096;
+__global__ __launch_bounds__(256) void posenc_sine_kernel(const unsigned char* __restrict__ mask, float* __restrict__ out,
+                                                          int H, int W, int F, float temperature, float scale) {
+    __shared__ float ye[POSENC_MAX_CELLS], xe[POSENC_MAX_CELLS];
+    const int b = blockIdx.x, tid = threadIdx.x, HW = H * W;
+    const unsigned char* m = mask ? mask + (long)b * HW : nullptr;
+    for (int x = tid; x < W; x += 256) {            // counts down a column
+        float run = 0.f;
+        for (int y = 0; y < H; ++y) {
+            run += (m && m[y * W + x]) ? 0.f : 1.f;
+            ye[y * W + x] = run;
+        }
+    }
+    for (int y = tid; y < H; y += 256) {            // counts along a row
+        float run = 0.f;
+        for (int x = 0; x < W; ++x) {
+            run += (m && m[y * W + x]) ? 0.f : 1.f;
+            xe[y * W + x] = run;
+        }
+    }
+    __syncthreads();
+    const int C = 2 * F;
+    float* o = out + (long)b * HW * C;
+    for (long i = tid; i < (long)HW * C; i += 256) {
+        const int t = (int)(i / C), c = (int)(i % C), y = t / W, x = t % W;
+        const int f = c < F ? c : c - F;
+        const float e = c < F ? ye[t] / (ye[(H - 1) * W + x] + 1e-6f) * scale : xe[t] / (xe[y * W + W - 1] + 1e-6f) * scale;
+        const float dim_t = powf(temperature, 2.f * (float)(f / 2) / (float)F);
+        const float a = e / dim_t;
+        o[i] = (f & 1) ? cosf(a) : sinf(a);
+    }
+}
+}  // namespace
+
+extern "C" int spot_posenc_sine_f32(const unsigned char* mask, float* out, int B, int H, int W, int num_pos_feats,
+                                    float temperature, float scale, hipStream_t stream) {
+    SPOT_CHECK_ARG(out && B >= 0 && H > 0 && W > 0 && num_pos_feats > 0, "posenc_sine: bad arguments");
+    SPOT_CHECK_ARG((long)H * W <= POSENC_MAX_CELLS, "posenc_sine: H*W=%ld beyond %d cells", (long)H * W, POSENC_MAX_CELLS);
+    if (B == 0) return SPOT_OK;
+    posenc_sine_kernel<<<B, 256, 0, stream>>>(mask, out, H, W, num_pos_feats, temperature, scale);
+    SPOT_CHECK_LAUNCH("posenc_sine");
+    return SPOT_OK;
+}

@@ -269,9 +269,18 @@ extern "C" int spot_gather_rows(const void* src, void* dst, const int* gather_id
 // Matcher (ltr/models/loss/transt_matcher.py:24-109): tokens whose cell index lies in
 // the ground-truth box are positives; a ring of width `gap` around them are the
 // IoU-head negatives.  The reference does this arithmetic in Python floats
-// (float64) on .item() values, hence the doubles.  One thread per token.
+// (float64) on .item() values, hence the doubles, and cuts the token grid with numpy
+// slices [a:b]: a bound below zero counts from the end (a box wholly left of or above
+// the map gives a negative upper bound), a bound above n is n.  The four rectangles of
+// the ring (:92-95) are disjoint for boxes on the map and may overlap once a bound has
+// wrapped, so the ring is returned as a multiplicity.  One thread per token.
 // ---------------------------------------------------------------------------
 namespace {
+__device__ __forceinline__ int np_bound(int i, int n) { return i < 0 ? max(i + n, 0) : min(i, n); }
+__device__ __forceinline__ bool np_rect(int y, int x, int y0, int y1, int x0, int x1, int n) {
+    return y >= np_bound(y0, n) && y < np_bound(y1, n) && x >= np_bound(x0, n) && x < np_bound(x1, n);
+}
+
 __global__ __launch_bounds__(256) void match_masks_kernel(const float* __restrict__ gt, int n, int gap,
                                                           unsigned char* __restrict__ pos,
                                                           unsigned char* __restrict__ neg, int B) {
@@ -284,14 +293,11 @@ __global__ __launch_bounds__(256) void match_masks_kernel(const float* __restric
     int X1 = min((int)ceil((cx + w / 2) * n), n), Y1 = min((int)ceil((cy + h / 2) * n), n);
     if (X0 == X1) X1 += 1;
     if (Y0 == Y1) Y1 += 1;
-    const bool p = y >= Y0 && y < Y1 && x >= X0 && x < X1;
-    pos[i] = p ? 1 : 0;
+    pos[i] = np_rect(y, x, Y0, Y1, X0, X1, n) ? 1 : 0;
     if (neg) {
         const int Yo0 = max(0, Y0 - gap), Yo1 = min(n, Y1 + gap), Xo0 = max(0, X0 - gap), Xo1 = min(n, X1 + gap);
-        const bool in_outer = y >= Yo0 && y < Yo1 && x >= Xo0 && x < Xo1;
-        // union of the four rectangles of :92-95 == outer rectangle minus [Y0,Y1) x [X0,X1)
-        const bool in_inner = y >= Y0 && y < Y1 && x >= X0 && x < X1;
-        neg[i] = (in_outer && !in_inner) ? 1 : 0;
+        neg[i] = (unsigned char)((int)np_rect(y, x, Yo0, Yo1, Xo0, X0, n) + (int)np_rect(y, x, Yo0, Y0, X0, X1, n) +
+                                 (int)np_rect(y, x, Y1, Yo1, X0, X1, n) + (int)np_rect(y, x, Yo0, Yo1, X1, Xo1, n));
     }
 }
 }  // namespace

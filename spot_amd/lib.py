@@ -52,6 +52,7 @@ class WinogradOpts(C.Structure):
 # name -> argument ctypes (all return int unless noted); the trailing hipStream_t is a void*
 SIGNATURES = {
     "spot_preprocess_u8_f32": [vp, vp, C.POINTER(f32), C.POINTER(f32), vp, i32, i32, i32, i32, vp],
+    "spot_posenc_sine_f32": [vp, vp, i32, i32, i32, i32, f32, f32, vp],
     "spot_decode_teacher_f32": [vp, vp, vp, vp, f64, i32, i32, vp, vp, vp, vp, i32, i32, vp],
     "spot_middleware_filter_f32": [vp, vp, vp, vp, vp, vp, i32, f32, vp, vp, vp, i32, vp],
     "spot_decode_filter_f32": [vp, vp, vp, vp, f64, i32, i32, vp, vp, vp, vp, i32, f32,

@@ -290,7 +290,7 @@ def case_layer_bwd():
          ds1=t2n(s1.grad), ds2=t2n(s2.grad), **grads)
 
 
-def case_teacher(B=8, seed=1):
+def case_teacher(B=8, seed=1, name="g5_teacher", slice_step=1):
     """G5: teacher forward -> decode -> middleware filter (cfg-2 shapes, eval mode)."""
     import ltr.actor as actors
     from ltr.utils import TensorDict
@@ -308,7 +308,13 @@ def case_teacher(B=8, seed=1):
         conf = pseudo0["best_conf"]
         logit = torch.log(conf / (1 - conf))
         # tau lands in the middle of the gap between the two central samples
-        shift = float(np.log(0.85 / 0.15) - np.median(t2n(logit).astype(np.float64)))
+        lg = np.sort(t2n(logit).astype(np.float64))
+        if B <= 8:
+            shift = float(np.log(0.85 / 0.15) - np.median(lg))
+        else:                       # the widest of the gaps around the middle, so that no confidence sits on tau
+            lo, hi = B // 2 - 4, B // 2 + 3
+            j = lo + int(np.argmax(lg[lo + 1:hi + 1] - lg[lo:hi]))
+            shift = float(np.log(0.85 / 0.15) - 0.5 * (lg[j] + lg[j + 1]))
     det_shift = np.float32(shift)
     with torch.no_grad():
         net.iou_embed.layers[2].bias += det_shift
@@ -321,12 +327,120 @@ def case_teacher(B=8, seed=1):
     assert gap > 1e-3, "golden ill-conditioned: a confidence sits %g from tau" % gap
     mid = middle_inputs(B, seed)
     res = run_middleware(S, mid, pseudo)
-    save("g5_teacher", seed=seed, B=B, iou_bias_shift=det_shift,
-         pred_logits=t2n(raw["pred_logits"]), pred_boxes=t2n(raw["pred_boxes"]),
-         pred_ious=t2n(raw["pred_ious"]),
+    st = slice_step            # every st-th token of the maps (the decoded outputs cover the rest through the arg-max)
+    save(name, seed=seed, B=B, iou_bias_shift=det_shift, slice_step=st,
+         pred_logits=t2n(raw["pred_logits"])[:, ::st], pred_boxes=t2n(raw["pred_boxes"])[:, ::st],
+         pred_ious=t2n(raw["pred_ious"])[:, ::st],
          best_bbox=t2n(pseudo["best_bbox"]), best_score=t2n(pseudo["best_score"]),
          best_conf=t2n(pseudo["best_conf"]),
          aug_anno=t2n(res["aug_anno"]), aug_success=t2n(res["aug_success"]))
+
+
+def case_track(seed=5, n_frames=5):
+    """G21: the online API at the network boundary (transt_model.py:86-117 through the tracker of
+    pysot_toolkit/trackers/transt_tracker.py:108-193): the reference network in eval(), its template() on one seeded
+    128x128 crop, its track() on five seeded 256x256 crops, and the reference tracker's own normalisation, window
+    penalty, arg-max and state update around them.  The crops replace get_subwindow's result (cv2.resize is absent; the
+    crop windows themselves are pinned by G18), everything behind them is the reference's code."""
+    spec = importlib.util.spec_from_file_location(
+        "ref_transt_tracker", os.path.join(REF, "pysot_toolkit", "trackers", "transt_tracker.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    S = Settings()
+    model = build_transt(S, seed=seed).eval()
+    z = det_input("z_crop", (1, 3, 128, 128), seed, 0, 256, np.uint8)
+    xs = det_input("x_crops", (n_frames, 3, 256, 256), seed, 0, 256, np.uint8)
+    raw = []
+
+    class Net:                      # what net_wrappers.NetWithBackbone does around the model: eval(), no grad
+        def initialize(self):
+            pass
+
+        def template(self, zc):
+            with torch.no_grad():
+                model.template(zc)
+
+        def track(self, xc):
+            with torch.no_grad():
+                o = model.track(xc)
+            raw.append((t2n(o["pred_logits"]), t2n(o["pred_boxes"])))
+            return o
+
+    trk = mod.TransT_Tracker("g", Net(), window_penalty=0.49, exemplar_size=128, instance_size=256)
+    crops = [torch.from_numpy(z.astype(np.float32))] + [torch.from_numpy(x[None].astype(np.float32)) for x in xs]
+    trk.get_subwindow = lambda im, pos, msz, osz, avg: crops.pop(0).clone()
+    img = np.zeros((300, 400, 3), np.uint8)
+    trk.initialize(img, {"init_bbox": [150.0, 100.0, 60.0, 40.0]})
+    bbox, best, centers, sizes = [], [], [], []
+    for i in range(n_frames):
+        o = trk.track(img)
+        bbox.append(o["target_bbox"])
+        best.append(float(np.max(o["best_score"])))
+        centers.append(trk.center_pos.copy())
+        sizes.append(trk.size.copy())
+    save("g21_track", seed=seed, n_frames=n_frames, init_bbox=[150.0, 100.0, 60.0, 40.0], image_hw=[300, 400],
+         pred_logits=np.concatenate([r[0] for r in raw]), pred_boxes=np.concatenate([r[1] for r in raw]),
+         target_bbox=np.array(bbox), best=np.array(best), center=np.array(centers), size=np.array(sizes))
+
+
+def case_matcher_offmap():
+    """G22: matcher index sets (and the losses built on them) for boxes that leave the 32x32 map: partly and wholly
+    beyond each side (a wholly negative corner makes the reference's numpy slices wrap around), zero-sized boxes whose
+    cell range is empty (Xmin == Xmax), boxes on the last row / column, a box covering everything."""
+    from ltr.models.loss.transt_matcher import TrackingMatcher
+    from ltr.models.tracking.transt_criterion import SetCriterionTransT
+    S = Settings()
+    L = 1024
+    gt = np.array([[-0.20, 0.50, 0.10, 0.20],      # wholly left of the map: Xmax < 0
+                   [0.50, -0.30, 0.30, 0.20],      # wholly above
+                   [1.30, 0.40, 0.20, 0.20],       # wholly right: Xmin > 32
+                   [0.40, 1.25, 0.20, 0.10],       # wholly below
+                   [-0.02, -0.02, 0.10, 0.10],     # straddles the top-left corner
+                   [1.00, 1.00, 0.10, 0.10],       # straddles the bottom-right corner
+                   [0.999, 0.5, 0.0, 0.0],         # empty range on the last column
+                   [0.5, 0.5, 0.0, 0.0],           # empty range in the middle (cell boundary)
+                   [0.03125, 0.0625, 0.0, 0.0],    # empty range exactly on a cell edge
+                   [0.5, 0.5, 3.0, 3.0],           # covers everything
+                   [-0.06, 0.5, 0.04, 1.5],        # left of the map, taller than it
+                   [0.984375, 0.015625, 0.03125, 0.03125]], np.float32)   # the top-right cell exactly
+    B = gt.shape[0]
+    logits = det_input("logits", (B, L, 2), 53, -2, 2)
+    boxes = det_input("boxes", (B, L, 4), 53, 0.05, 0.6)
+    ious = det_input("ious", (B, L, 1), 53, 0.0, 1.0)
+    m = TrackingMatcher()
+    crit = SetCriterionTransT(S, m)
+    out = {}
+    for tag in ("sup", "unsup"):
+        o = {"logits_" + tag: torch.from_numpy(logits.copy()).requires_grad_(),
+             "boxes_" + tag: torch.from_numpy(boxes.copy()).requires_grad_()}
+        if tag == "sup":
+            o["ious_" + tag] = torch.from_numpy(ious.copy()).requires_grad_()
+        ind, ind_neg = m(o, _targets_from(gt), tag=tag)
+        pos_cnt = np.zeros((B, L), np.int32)
+        neg_cnt = np.zeros((B, L), np.int32)
+        for i, (src, _) in enumerate(ind):
+            np.add.at(pos_cnt[i], src.numpy(), 1)
+        if ind_neg is not None:
+            for i, (src, _) in enumerate(ind_neg):
+                np.add.at(neg_cnt[i], src.numpy(), 1)
+        assert pos_cnt.max() <= 1
+        out["pos_mask_" + tag] = pos_cnt.astype(bool)
+        out["neg_count_" + tag] = neg_cnt
+        losses = crit(o, _targets_from(gt), tag=tag)
+        wd = S.weight_dict
+        total = sum(losses[k] * wd[k + "_" + tag] for k in losses if k + "_" + tag in wd)
+        total.backward()
+        for k, v in losses.items():
+            out["%s_%s" % (k, tag)] = t2n(v)
+        out["total_" + tag] = t2n(total)
+        for k, v in o.items():
+            out["grad_" + k] = t2n(v.grad)
+    save("g22_matcher_offmap", seed=53, gt=gt, **out)
+
+
+def case_teacher_b32():
+    """G5 at the benchmark configuration's batch (32 clips): decoded outputs, keep mask and a slice of the maps."""
+    case_teacher(B=32, seed=1, name="g5_teacher_b32", slice_step=4)
 
 
 def case_decode():
@@ -883,6 +997,12 @@ def case_student(seed=3):
         g = t2n(sd[k].grad)
         out["gnorm." + k] = np.linalg.norm(g)
         out["gslice." + k] = g.reshape(-1)[:64]
+    # every parameter of the fusion network and the heads: <= 2048 evenly strided elements of its gradient
+    for k, p_ in sd.items():
+        if p_.grad is not None and k.startswith(("featurefusion_network.", "class_embed.", "bbox_embed.", "iou_embed.",
+                                                 "input_proj.")):
+            g = t2n(p_.grad).reshape(-1)
+            out["gsub." + k] = g[::max(1, g.size // 2048)]
     allnorm = {k: float(np.linalg.norm(t2n(p.grad))) for k, p in sd.items() if p.grad is not None}
     save("g15_student", seed=seed, bs=bs, bu=bu, loss=t2n(loss), search_anno=search_anno,
          aug_anno=aug_anno, stat_keys=list(stats.keys()), stat_vals=[stats[k] for k in stats],
@@ -895,6 +1015,7 @@ CASES = {
     "matcher_criterion": case_matcher_criterion, "tracker_post": case_tracker_post,
     "xcorr": case_xcorr, "ema": case_ema, "pre_pos": case_preprocess_posenc,
     "student": case_student, "transforms": case_transforms, "ocean": case_ocean, "ocean_tracker": case_ocean_tracker, "ocean_model": case_ocean_model, "crop": case_crop,
+    "track": case_track, "matcher_offmap": case_matcher_offmap, "teacher_b32": case_teacher_b32,
 }
 
 

@@ -841,3 +841,60 @@ def test_mha_forward_with_split_keys(ops, Lq, Lk, nsplit):
     auto, lse = ops.mha_core_fwd(qg, C, kg, C, vg, C, B, Lq, Lk, nh, dh, kp, False)   # the wrapper's own choice
     assert lse is None
     np.testing.assert_allclose(auto.cpu().numpy(), one.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+# --------------------------------------------------------------------------- position encoding, matcher, criterion
+def test_position_encoding_golden(golden):
+    """The sine position encoding kernel against the reference's PositionEmbeddingSine: the unmasked 16x16 and 32x32
+    maps of the template / search tokens (as the cached token rows the network reads) and a masked 8x8 map."""
+    from spot_amd.backbone import PositionEmbeddingSine
+    from spot_amd.tensordict import NestedTensor
+    g = golden("g14_pre_pos")
+    pe = PositionEmbeddingSine(128, normalize=True)
+    for hw in (16, 32):
+        rows = pe.rows(hw, hw, torch.device(DEV))                        # [H*W, 256]
+        ref = g["pos%d" % hw][0].reshape(256, hw * hw).T
+        np.testing.assert_allclose(rows.cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
+        assert pe.rows(hw, hw, torch.device(DEV)) is rows                # kept per (H, W, device)
+    mask = G(g["mask8"])
+    out = pe(NestedTensor(torch.zeros(1, 1, 8, 8, device=DEV), mask))
+    np.testing.assert_allclose(out.cpu().numpy(), g["pos8_masked"], rtol=1e-5, atol=2e-6)
+    both = pe(NestedTensor(None, torch.cat([mask, torch.zeros_like(mask)])))     # clips do not interact
+    assert torch.equal(both[0], out[0])
+    np.testing.assert_allclose(both[1].cpu().numpy(), O.position_embedding_sine(torch.zeros(1, 8, 8, dtype=torch.bool))[0].numpy(),
+                               rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name,seed", [("g9_matcher_criterion", 51), ("g22_matcher_offmap", 53)])
+def test_matcher_masks_and_criterion_golden(golden, name, seed):
+    """spot_match_masks on the reference's border cases (boxes at the map's edge, beyond it on every side, empty cell
+    ranges, the whole map): token sets identical to the reference matcher's index lists; the losses built on them and
+    their gradients against the reference criterion."""
+    from spot_amd.criterion import transt_loss
+    from spot_amd.synthetic import Settings
+    g = golden(name)
+    gt = g["gt"]
+    B, L = gt.shape[0], 1024
+    crit = transt_loss(Settings()).to(DEV)
+    logits, boxes = det_input("logits", (B, L, 2), seed, -2, 2), det_input("boxes", (B, L, 4), seed, 0.05, 0.6)
+    ious = det_input("ious", (B, L, 1), seed, 0.0, 1.0)
+    wd = Settings().weight_dict
+    for tag in ("sup", "unsup"):
+        o = {"logits_" + tag: G(logits).requires_grad_(), "boxes_" + tag: G(boxes).requires_grad_()}
+        if tag == "sup":
+            o["ious_" + tag] = G(ious).requires_grad_()
+        pos, neg = crit.matcher(o, G(gt), tag=tag)
+        assert np.array_equal(pos.cpu().numpy(), g["pos_mask_" + tag])
+        if tag == "sup":
+            assert np.array_equal(neg.cpu().numpy().astype(np.int32), g["neg_count_" + tag])
+        else:
+            assert neg is None
+        losses = crit(o, G(gt), tag=tag)
+        for k, v in losses.items():
+            np.testing.assert_allclose(v.item(), g["%s_%s" % (k, tag)], rtol=2e-5, err_msg=k)
+        total = sum(losses[k] * wd[k + "_" + tag] for k in losses if k + "_" + tag in wd)
+        np.testing.assert_allclose(total.item(), g["total_" + tag], rtol=2e-5)
+        total.backward()
+        for k, v in o.items():
+            ref = g["grad_" + k]
+            np.testing.assert_allclose(v.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-6 * float(np.abs(ref).max()), err_msg=k)

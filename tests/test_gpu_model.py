@@ -66,6 +66,41 @@ def test_teacher_pseudo_label_pipeline_golden(golden):
     np.testing.assert_allclose(res["aug_anno"].cpu().numpy(), g["aug_anno"], atol=0.5)
 
 
+def test_teacher_pseudo_label_pipeline_golden_at_benchmark_batch(golden):
+    """The benchmark configuration's 32-clip pseudo-labelling pass against the reference's outputs: every 4th token of
+    the maps, every decoded box / score / confidence, the re-projected boxes and the keep mask."""
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.middleware import SparseMiddleware
+    from spot_amd.tensordict import TensorDict
+    from tests.test_oracle_model import teacher_b32_inputs
+    g = golden("g5_teacher_b32")
+    B, seed, st = int(g["B"]), int(g["seed"]), int(g["slice_step"])
+    S = Settings()
+    net = build(seed).eval()
+    with torch.no_grad():
+        net.iou_embed.layers[2].bias += float(g["iou_bias_shift"])
+    actor = TranstSparseActor(S, net, net, None)
+    key, unl, mid = teacher_b32_inputs(g)
+    data = TensorDict({"key_images": key.to(DEV), "unlabeled_images": unl.to(DEV),
+                       "key_avg": G(det_input("key_avg", (B, 3), seed, 0, 255)),
+                       "unlabeled_avg": G(det_input("unlabeled_avg", (B, 3), seed, 0, 255)),
+                       "key_anno": G(det_input("key_anno", (B, 4), seed, 20, 80)),
+                       "unlabeled_anno": G(det_input("unlabeled_anno", (B, 4), seed, 40, 120))})
+    with torch.no_grad():
+        raw = net(teacher_data=TensorDict(data))
+    np.testing.assert_allclose(raw["pred_logits"].cpu().numpy()[:, ::st], g["pred_logits"], rtol=1e-3, atol=5e-4)
+    np.testing.assert_allclose(raw["pred_boxes"].cpu().numpy()[:, ::st], g["pred_boxes"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(raw["pred_ious"].cpu().numpy()[:, ::st], g["pred_ious"], rtol=1e-3, atol=1e-4)
+    pseudo = actor(mode="inference", teacher_data=TensorDict(data))
+    np.testing.assert_allclose(pseudo["best_bbox"].cpu().numpy(), g["best_bbox"], atol=0.5)       # 0.5 px
+    np.testing.assert_allclose(pseudo["best_score"].cpu().numpy(), g["best_score"], rtol=1e-3)
+    np.testing.assert_allclose(pseudo["best_conf"].cpu().numpy(), g["best_conf"], rtol=1e-3)
+    res = SparseMiddleware(S).record_relay_results(mid, pseudo)
+    assert np.array_equal(res["aug_success"].cpu().numpy(), g["aug_success"])                     # identical keep mask
+    assert 0 < int(g["aug_success"].sum()) < B
+    np.testing.assert_allclose(res["aug_anno"].cpu().numpy(), g["aug_anno"], atol=0.5)
+
+
 def test_sharded_pseudo_labelling_equals_single_batch():
     """Pseudo-labelling + filtering of a clip set cut into contiguous per-rank blocks (dist.shard_range) gives the
     result of one big batch: the teacher runs in eval mode, so clips do not interact and no collective is needed."""
@@ -92,16 +127,12 @@ def test_sharded_pseudo_labelling_equals_single_batch():
         net.iou_embed.layers[2].bias += float(np.log(0.85 / 0.15)) - torch.log(conf / (1 - conf)).median()
         full_p, full_r = run(0, n_clips)
         parts = [run(*shard_range(n_clips, r, world)) for r in range(world)]
-    keep = torch.cat([r["aug_success"] for _, r in parts])
-    conf = torch.cat([p["best_conf"] for p, _ in parts])
-    near = (full_p["best_conf"] - 0.85).abs() < 1e-4          # a different conv algorithm may move a tie
-    assert bool(((keep == full_r["aug_success"]) | near).all())
+    # no kernel on this path lets clips interact or picks its arithmetic by batch size: bit-identical results
     assert 0 < int(full_r["aug_success"].sum()) < n_clips
-    np.testing.assert_allclose(conf.cpu().numpy(), full_p["best_conf"].cpu().numpy(), rtol=1e-3)
-    np.testing.assert_allclose(torch.cat([p["best_bbox"] for p, _ in parts]).cpu().numpy(),
-                               full_p["best_bbox"].cpu().numpy(), atol=0.5)
-    np.testing.assert_allclose(torch.cat([r["aug_anno"] for _, r in parts]).cpu().numpy(),
-                               full_r["aug_anno"].cpu().numpy(), atol=0.5)
+    for k in ("best_bbox", "best_score", "best_conf"):
+        assert torch.equal(torch.cat([p[k] for p, _ in parts]), full_p[k]), k
+    for k in ("aug_success", "aug_anno"):
+        assert torch.equal(torch.cat([r[k] for _, r in parts]), full_r[k]), k
 
 
 def test_student_step_golden(golden):
@@ -132,6 +163,10 @@ def test_student_step_golden(golden):
         ref = g["gslice." + k]
         np.testing.assert_allclose(params[k].grad.reshape(-1)[:64].cpu().numpy(), ref, rtol=2e-2,
                                    atol=2e-3 * max(1e-6, float(np.abs(ref).max())), err_msg=k)
+    # every gradient tensor of the fusion network, input_proj and the heads against the reference's samples of it:
+    # cosine >= 0.9999 each, largest deviation <= 2e-3 of the tensor's largest sample
+    from tests.test_oracle_model import check_gradient_samples
+    check_gradient_samples(g, {k: p.grad for k, p in params.items() if p.grad is not None})
 
 
 def test_two_stream_forward_matches_sequential_including_running_stats():
@@ -160,7 +195,7 @@ def test_two_stream_forward_matches_sequential_including_running_stats():
     for k in s0:
         if "tracked" in k:
             assert torch.equal(s0[k], s1[k]), k
-        else:       # the convolution library may pick another algorithm on the second stream: rounding-level spread
+        else:       # batch statistics are summed by float atomics whose order differs from run to run
             np.testing.assert_allclose(s0[k].cpu().numpy(), s1[k].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
     assert int(s1["backbone.0.body.bn1.num_batches_tracked"]) == 4      # search + template, twice
     for k in ("logits_sup", "boxes_unsup"):
@@ -315,6 +350,40 @@ def test_tracker_post_processing_golden(golden):
         np.testing.assert_allclose(np.max(o["best_score"]), g["best"][i], rtol=1e-6)
         np.testing.assert_allclose(trk.center_pos, g["center"][i], rtol=1e-6, atol=1e-3)
         np.testing.assert_allclose(trk.size, g["size"][i], rtol=1e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_online_template_track_golden(golden, use_graph):
+    """TransT.template / TransT.track at the network boundary against the reference's (transt_model.py:86-117 inside
+    the tracker of transt_tracker.py:108-193): the network holder's frozen-weight path (kept position tables and
+    transformed weights, folded inference BatchNorm, split-key attention), eagerly and, from the third frame, as the
+    replayed HIP graph.  The crops stand in for get_subwindow's result on both sides."""
+    from spot_amd.tracker import NetWithBackbone, TransT_Tracker
+    g = golden("g21_track")
+    seed, n = int(g["seed"]), int(g["n_frames"])
+
+    class Recording(NetWithBackbone):
+        def track(self, x):
+            self.__dict__["last"] = NetWithBackbone.track(self, x)       # inside a graph: the replayed output buffers
+            return self.__dict__["last"]
+
+    net = Recording(net=build(seed), use_gpu=True)
+    trk = TransT_Tracker("g", net, window_penalty=0.49, exemplar_size=128, instance_size=256, use_graph=use_graph)
+    crops = [G(det_input("z_crop", (1, 3, 128, 128), seed, 0, 256, np.uint8))]
+    crops += list(G(det_input("x_crops", (n, 3, 256, 256), seed, 0, 256, np.uint8)).unsqueeze(1))
+    trk.get_subwindow = lambda im, pos, msz, osz, avg: crops.pop(0)
+    img = np.zeros((int(g["image_hw"][0]), int(g["image_hw"][1]), 3), np.uint8)
+    trk.initialize(img, {"init_bbox": [float(v) for v in g["init_bbox"]]})
+    for i in range(n):
+        o = trk.track(img)
+        last = net.__dict__["last"]
+        np.testing.assert_allclose(last["pred_logits"].cpu().numpy()[0], g["pred_logits"][i], rtol=1e-3, atol=5e-4)
+        np.testing.assert_allclose(last["pred_boxes"].cpu().numpy()[0], g["pred_boxes"][i], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(o["target_bbox"], g["target_bbox"][i], atol=0.5)                # 0.5 px
+        np.testing.assert_allclose(np.max(o["best_score"]), g["best"][i], rtol=1e-3)
+        np.testing.assert_allclose(trk.center_pos, g["center"][i], atol=0.5)
+        np.testing.assert_allclose(trk.size, g["size"][i], atol=0.5)
+    assert (trk._graph is not None) == use_graph
 
 
 def test_tracker_graph_replay_equals_eager():

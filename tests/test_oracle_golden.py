@@ -176,6 +176,28 @@ def test_matcher_and_criterion(golden):
             np.testing.assert_allclose(io.grad.numpy(), g["grad_ious_" + tag], rtol=1e-4, atol=1e-8)
 
 
+def test_matcher_and_criterion_for_boxes_off_the_map(golden):
+    """Boxes partly and wholly beyond the 32x32 map (the reference's numpy slices wrap for negative bounds), empty cell ranges, the whole map."""
+    g = golden("g22_matcher_offmap")
+    gt = g["gt"]
+    B, L = gt.shape[0], 1024
+    logits = det_input("logits", (B, L, 2), 53, -2, 2)
+    boxes = det_input("boxes", (B, L, 4), 53, 0.05, 0.6)
+    ious = det_input("ious", (B, L, 1), 53, 0.0, 1.0)
+    # the cases are really in there: a wrapped slice (box 0 lies left of the map, its positives are columns 0..27),
+    # an empty set (box 2 lies right of it)
+    assert g["pos_mask_sup"][0].reshape(32, 32)[16, :28].all() and not g["pos_mask_sup"][2].any()
+    for tag in ("sup", "unsup"):
+        pos, neg = O.matcher_masks(gt, L, with_neg=(tag == "sup"))
+        assert np.array_equal(pos, g["pos_mask_" + tag])
+        assert np.array_equal(neg, g["neg_count_" + tag])
+        lg, bx = T(logits).requires_grad_(), T(boxes).requires_grad_()
+        io = T(ious).requires_grad_() if tag == "sup" else None
+        losses = O.criterion(lg, bx, io, T(gt), 0.0625, tag)
+        for k, v in losses.items():
+            np.testing.assert_allclose(v.detach().numpy(), g["%s_%s" % (k, tag)], rtol=2e-5, err_msg=k)
+
+
 def test_tracker_post(golden):
     g = golden("g11_tracker_post")
     bb = g["init_bbox"]

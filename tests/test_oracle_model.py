@@ -88,3 +88,104 @@ def test_student_step_golden(golden):
         ref = g["gslice." + k]
         np.testing.assert_allclose(sd[k].grad.reshape(-1)[:64].numpy(), ref, rtol=2e-2,
                                    atol=2e-3 * max(1e-6, float(np.abs(ref).max())), err_msg=k)
+
+
+def test_student_step_gradient_samples_golden(golden):
+    """Every parameter of the fusion network, input_proj and the heads: the evenly strided gradient samples the
+    reference produced, compared direction and size."""
+    g = golden("g15_student")
+    seed, bs, bu = int(g["seed"]), int(g["bs"]), int(g["bu"])
+    sd = model_sd(seed, requires_grad=True)
+    sup, sp = student_batches(seed, bs, bu)
+    template = torch.cat([sup["template_images"], sp["relay_images"]])
+    search = torch.cat([sup["search_images"], sp["aug_images"]])
+    out = O.transt_forward(template, search, sd, b_iou=bs, training=True)
+    o_sup = {"logits": out["pred_logits"][:bs], "boxes": out["pred_boxes"][:bs], "ious": out["pred_ious"]}
+    o_un = {"logits": out["pred_logits"][bs:], "boxes": out["pred_boxes"][bs:]}
+    loss, _, _ = O.sp_training_loss(o_sup, o_un, sup["search_anno"], sp["aug_anno"], Settings().weight_dict)
+    loss.backward()
+    check_gradient_samples(g, {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None})
+
+
+def check_gradient_samples(g, grads, cos_min=0.9999, rel_max=2e-3):
+    """grads: name -> gradient tensor.  Against the golden's `gsub.<name>` samples (<= 2048 evenly strided elements
+    of each gradient): cosine >= cos_min per tensor and over all samples together, and the largest deviation
+    <= rel_max of the tensor's largest sample."""
+    names = [n[len("gsub."):] for n in g.files if n.startswith("gsub.")]
+    assert len(names) > 100
+    all_a, all_b = [], []
+    for k in names:
+        ref = g["gsub." + k].astype(np.float64)
+        got = grads[k].detach().reshape(-1).cpu().double().numpy()
+        got = got[::max(1, got.size // 2048)]
+        assert got.shape == ref.shape, k
+        scale = np.abs(ref).max()
+        if scale < 1e-12:
+            assert np.abs(got).max() < 1e-9, k
+            continue
+        cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref)))
+        assert cos >= cos_min, (k, cos)
+        assert np.abs(got - ref).max() <= rel_max * scale, (k, np.abs(got - ref).max() / scale)
+        all_a.append(got / scale)
+        all_b.append(ref / scale)
+    a, b = np.concatenate(all_a), np.concatenate(all_b)
+    assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) >= 0.99999
+
+
+def teacher_b32_inputs(g):
+    B, seed = int(g["B"]), int(g["seed"])
+    key = det_input("key_images", (B, 3, 128, 128), seed, 0, 256, np.uint8)
+    unl = det_input("unlabeled_images", (B, 3, 256, 256), seed, 0, 256, np.uint8)
+    xy, wh = det_input("unl_xy", (B, 1, 2), seed, 0, 400), det_input("unl_wh", (B, 1, 2), seed, 20, 200)
+    ue = np.concatenate([xy, wh], -1).astype(np.float32)
+    xy, wh = det_input("aug_xy", (B, 1, 2), seed, 0, 400), det_input("aug_wh", (B, 1, 2), seed, 20, 200)
+    ae = np.concatenate([xy, wh], -1).astype(np.float32)
+    mid = {"unlabeled_box_extract": T(ue), "unlabeled_resize_factors": T(det_input("unl_rf", (B,), seed, 0.5, 2.0)),
+           "aug_box_extract": T(ae), "aug_resize_factors": T(det_input("aug_rf", (B,), seed, 0.5, 2.0))}
+    return T(key), T(unl), mid
+
+
+def test_teacher_pipeline_golden_at_benchmark_batch(golden):
+    """The 32-clip pseudo-labelling pass of the benchmark configuration against the reference's outputs."""
+    g = golden("g5_teacher_b32")
+    B, seed, st = int(g["B"]), int(g["seed"]), int(g["slice_step"])
+    assert B == 32
+    sd = model_sd(seed)
+    sd["iou_embed.layers.2.bias"] = sd["iou_embed.layers.2.bias"] + float(g["iou_bias_shift"])
+    key, unl, mid = teacher_b32_inputs(g)
+    with torch.no_grad():
+        out = O.transt_forward(key, unl, sd)
+    np.testing.assert_allclose(out["pred_logits"].numpy()[:, ::st], g["pred_logits"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(out["pred_boxes"].numpy()[:, ::st], g["pred_boxes"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(out["pred_ious"].numpy()[:, ::st], g["pred_ious"], rtol=1e-3, atol=1e-4)
+    dec = O.decode_teacher(out["pred_logits"], out["pred_boxes"], out["pred_ious"], 0.40, 32, 256, 256)
+    np.testing.assert_allclose(dec["best_bbox"].numpy(), g["best_bbox"], atol=0.5)
+    np.testing.assert_allclose(dec["best_score"].numpy(), g["best_score"], rtol=1e-3)
+    np.testing.assert_allclose(dec["best_conf"].numpy(), g["best_conf"], rtol=1e-3)
+    res = O.middleware_filter(dec["best_bbox"], dec["best_conf"], mid["unlabeled_box_extract"],
+                              mid["unlabeled_resize_factors"], mid["aug_box_extract"], mid["aug_resize_factors"], 256, 0.85)
+    assert np.array_equal(res["aug_success"].numpy(), g["aug_success"])
+    assert 0 < int(g["aug_success"].sum()) < B
+    np.testing.assert_allclose(res["aug_anno"].numpy(), g["aug_anno"], atol=0.5)
+
+
+def test_online_template_track_golden(golden):
+    """TransT.template / TransT.track at the network boundary and the tracker's state update over five frames."""
+    g = golden("g21_track")
+    seed, n = int(g["seed"]), int(g["n_frames"])
+    sd = model_sd(seed)
+    z = T(det_input("z_crop", (1, 3, 128, 128), seed, 0, 256, np.uint8))
+    xs = T(det_input("x_crops", (n, 3, 256, 256), seed, 0, 256, np.uint8))
+    bb = g["init_bbox"]
+    center, size = np.array([bb[0] + bb[2] / 2, bb[1] + bb[3] / 2]), np.array([bb[2], bb[3]])
+    h = np.hanning(32)
+    window = np.outer(h, h).flatten()
+    for i in range(n):
+        with torch.no_grad():
+            out = O.transt_forward(z, xs[i:i + 1], sd)
+        np.testing.assert_allclose(out["pred_logits"].numpy()[0], g["pred_logits"][i], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(out["pred_boxes"].numpy()[0], g["pred_boxes"][i], rtol=1e-3, atol=1e-4)
+        bbox, pscore, center, size, _ = O.tracker_post(out["pred_logits"].numpy()[0], out["pred_boxes"].numpy()[0], window,
+                                                       0.49, center, size, tuple(g["image_hw"]))
+        np.testing.assert_allclose(bbox, g["target_bbox"][i], atol=0.5)
+        np.testing.assert_allclose(pscore.max(), g["best"][i], rtol=1e-3)
