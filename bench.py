@@ -9,6 +9,7 @@ value = clips pseudo-labelled AND trained on per second, whole job (all ranks).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...        (no launcher: starts the N ranks itself, one fresh process per GPU)
 """
 import argparse
 import json
@@ -27,7 +28,18 @@ PEAK_HBM_GBS = 8000.0
 
 
 def build_world(args):
+    """This process's place in the job.  A rank launched for --gpus N whose device does not exist says how many GPUs
+    the job needs; a world size that is not --gpus N is a launcher mistake and says so."""
     from spot_amd import dist as sdist
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); start it as `python "
+                         "bench.py --gpus %d` or under torchrun with --nproc-per-node %d"
+                         % (args.gpus, world_env, args.gpus, args.gpus))
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py: --gpus %d needs %d GPUs on this node, found %d (rank %s)"
+                         % (args.gpus, args.gpus, have, os.environ.get("RANK", "0")))
     rank, world, local = sdist.init_from_env("nccl")
     torch.cuda.set_device(local)
     return rank, world, local
@@ -178,11 +190,16 @@ def main():
                          "bracketing all six costs about 2 %% of the step")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher: this process becomes the launcher.  It has made no GPU call (importing torch
+        # makes none) and makes none: the N ranks are fresh child processes, rank r on GPU r, over RCCL.
+        from spot_amd.dist import launch_local
+        sys.exit(launch_local(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+
     from spot_amd import lib, ops
     from spot_amd.tensordict import TensorDict
     lib.load()
     rank, world, local = build_world(args)
-    assert world == args.gpus, "launch with torchrun --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus)
     S, trainer, data_sup, data_unsup, mid = build_job(args, rank)
 
     from spot_amd import dist as sdist
@@ -233,10 +250,15 @@ def main():
         torch.cuda.synchronize()
         ops.TIMER = None
         fusion.TWO_STREAMS = two
+    per_rank_ms = [el / args.steps * 1e3]
+    comm_ranks = 1
     if collective:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        comm_ranks = dist.get_world_size()
+        mine = torch.tensor([el], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(comm_ranks)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        el = max(float(t.item()) for t in every)              # the job is as slow as its slowest rank
     done = args.steps - (trainer.skipped - skipped0)
 
     if rank == 0:
@@ -285,7 +307,8 @@ def main():
                                    % (args.clips, args.sup, args.clips, "" if args.attention == "f32" else
                                       " with bf16 attention products", args.dropout),
                        "clips_per_gpu": args.clips, "sup_pairs_per_gpu": args.sup, "skipped_steps": args.steps - done,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world, "communicator_ranks": comm_ranks,
+                       "ms_per_step_per_rank": [round(v, 3) for v in per_rank_ms]},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line))

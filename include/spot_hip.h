@@ -84,7 +84,8 @@ int spot_decode_filter_f32(const float* pred_logits, const float* pred_boxes, co
 int spot_compact_indices(const unsigned char* aug_success, int n_in, int* gather_idx, int n_out,
                          int* n_keep, hipStream_t stream);
 
-/* dst[r] = src[gather_idx[r]] for rows of row_bytes bytes (the torch.stack/cat of :342-357). */
+/* dst[r] = src[gather_idx[r]] for rows of row_bytes bytes (the torch.stack/cat of :342-357); a row whose index is
+ * negative (nothing was kept) is filled with zero bytes. */
 int spot_gather_rows(const void* src, void* dst, const int* gather_idx, int n_rows, long row_bytes,
                      hipStream_t stream);
 
@@ -483,6 +484,13 @@ typedef struct spot_adamw_groups {
 int spot_adamw_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                    const spot_adamw_chunk* chunks_dev, int n_chunks, const spot_adamw_groups* hyper,
                    hipStream_t stream);
+
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm) over flat gradient storage, as the trainer applies it to the
+ * Siamese variant after backward (ltr/trainers/ltr_sparse_trainer.py:75-80,126-131): norm_out[0] (device) = the L2 norm
+ * of grads[0..n); grads *= max_norm / (norm + 1e-6) when that is below 1 and the norm is finite (max_norm <= 0: the norm
+ * only).  Deterministic (no atomics).  ws: spot_clip_grad_norm_ws_floats() floats.  n a multiple of 4. */
+long spot_clip_grad_norm_ws_floats(void);
+int spot_clip_grad_norm_f32(float* grads, long n, float max_norm, float* norm_out, float* ws, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -413,3 +413,63 @@ extern "C" int spot_posenc_sine_f32(const unsigned char* mask, float* out, int B
     SPOT_CHECK_LAUNCH("posenc_sine");
     return SPOT_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Global gradient norm and clipping over the flat gradient buffer (torch.nn.utils.clip_grad_norm_(parameters, max_norm)
+// as the trainer applies it to the Siamese variant, ltr/trainers/ltr_sparse_trainer.py:126-131): norm = sqrt(sum g^2)
+// (block partials in float, their sum in double, no atomics: the same bits on every run and every rank),
+// g *= max_norm / (norm + 1e-6) when that factor is below 1 and the norm is finite.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int NORM_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float4* __restrict__ g, long n4, float* __restrict__ part) {
+    __shared__ float s[4];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = g[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+__global__ __launch_bounds__(256) void norm_finish_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ norm_out) {
+    __shared__ double s[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += (double)part[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) norm_out[0] = (float)sqrt(s[0]);
+}
+__global__ __launch_bounds__(256) void clip_scale_kernel(float4* __restrict__ g, long n4, const float* __restrict__ norm, float max_norm) {
+    const float nv = norm[0];
+    const float coef = max_norm / (nv + 1e-6f);
+    if (!(nv == nv) || nv > 3.0e38f || !(coef < 1.f)) return;          // non-finite norm: the caller skips the step
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 v = g[i];
+        v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
+        g[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" long spot_clip_grad_norm_ws_floats(void) { return NORM_BLOCKS; }
+
+extern "C" int spot_clip_grad_norm_f32(float* grads, long n, float max_norm, float* norm_out, float* ws, hipStream_t stream) {
+    SPOT_CHECK_ARG(grads && norm_out && ws && n >= 0, "clip_grad_norm: bad arguments");
+    SPOT_CHECK_ARG(n % 4 == 0 && ((uintptr_t)grads & 15) == 0, "clip_grad_norm: the buffer must be 16-byte aligned with a length that is a multiple of 4");
+    sumsq_partial_kernel<<<NORM_BLOCKS, 256, 0, stream>>>((const float4*)grads, n / 4, ws);
+    SPOT_CHECK_LAUNCH("clip_grad_norm(partials)");
+    norm_finish_kernel<<<1, 256, 0, stream>>>(ws, NORM_BLOCKS, norm_out);
+    SPOT_CHECK_LAUNCH("clip_grad_norm(finish)");
+    if (max_norm > 0.f) {
+        clip_scale_kernel<<<2048, 256, 0, stream>>>((float4*)grads, n / 4, norm_out, max_norm);
+        SPOT_CHECK_LAUNCH("clip_grad_norm(scale)");
+    }
+    return SPOT_OK;
+}

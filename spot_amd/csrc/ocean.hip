@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void ocean_tracker_decode_kernel(const float* 
         rc_r = fmax(rc_r, 1.0 / rc_r);
         const double pen = exp(-(rc_r * sc_r - 1.0) * penalty_k);
         const double ps = pen * (double)sc * (1.0 - window_influence) + window[i] * window_influence;
-        if (ps > best) {
+        // numpy.argmax order: the first NaN wins over every number, else the first maximum
+        if (best == best && (ps > best || ps != ps)) {
             best = ps;
             besti = i;
         }
@@ -88,7 +89,9 @@ __global__ __launch_bounds__(256) void ocean_tracker_decode_kernel(const float* 
         if ((int)threadIdx.x < o) {
             const double v = bv[threadIdx.x + o];
             const int j = bi[threadIdx.x + o];
-            if (v > bv[threadIdx.x] || (v == bv[threadIdx.x] && j < bi[threadIdx.x])) {
+            const double mine = bv[threadIdx.x];
+            const bool vn = v != v, mn = mine != mine;
+            if ((vn && (!mn || j < bi[threadIdx.x])) || (!vn && !mn && (v > mine || (v == mine && j < bi[threadIdx.x])))) {
                 bv[threadIdx.x] = v;
                 bi[threadIdx.x] = j;
             }

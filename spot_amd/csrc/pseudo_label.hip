@@ -26,7 +26,14 @@ struct Best {
 };
 
 __device__ __forceinline__ Best better(Best a, Best b) {
-    // larger value wins; on ties the smaller token index (first occurrence)
+    // larger value wins; on ties the smaller token index (first occurrence).  A NaN beats every number and the first
+    // NaN beats later ones, as torch.max / numpy.argmax order them: the chosen index always lies inside the clip's map
+    // (a diverged teacher gives conf = NaN, which fails the threshold, instead of an index no candidate ever set).
+    const bool an = a.v != a.v, bn = b.v != b.v;
+    if (an || bn) {
+        if (an && bn) return a.i < b.i ? a : b;
+        return an ? a : b;
+    }
     if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
     return a;
 }
@@ -158,9 +165,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restric
                                                           const int* __restrict__ idx, long row_vec) {
     const int r = blockIdx.y;
     const int s = idx[r];
-    if (s < 0) return;
-    const uint4* sp = src + (size_t)s * row_vec;
     uint4* dp = dst + (size_t)r * row_vec;
+    if (s < 0) {                 // no source row (nothing was kept): the row is defined, all zero bytes
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < row_vec; i += (long)gridDim.x * 256) dp[i] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const uint4* sp = src + (size_t)s * row_vec;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < row_vec; i += (long)gridDim.x * 256) dp[i] = sp[i];
 }
 
@@ -169,9 +179,12 @@ __global__ __launch_bounds__(256) void gather_rows_bytes_kernel(const unsigned c
                                                                 const int* __restrict__ idx, long row_bytes) {
     const int r = blockIdx.y;
     const int s = idx[r];
-    if (s < 0) return;
-    const unsigned char* sp = src + (size_t)s * row_bytes;
     unsigned char* dp = dst + (size_t)r * row_bytes;
+    if (s < 0) {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < row_bytes; i += (long)gridDim.x * 256) dp[i] = 0;
+        return;
+    }
+    const unsigned char* sp = src + (size_t)s * row_bytes;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < row_bytes; i += (long)gridDim.x * 256) dp[i] = sp[i];
 }
 
@@ -324,7 +337,12 @@ struct BestD {
     double v;
     int i;
 };
-__device__ __forceinline__ BestD better_d(BestD a, BestD b) {
+__device__ __forceinline__ BestD better_d(BestD a, BestD b) {       // numpy.argmax order: first NaN, else first maximum
+    const bool an = a.v != a.v, bn = b.v != b.v;
+    if (an || bn) {
+        if (an && bn) return a.i < b.i ? a : b;
+        return an ? a : b;
+    }
     if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
     return a;
 }
@@ -336,7 +354,7 @@ __global__ __launch_bounds__(256) void tracker_decode_kernel(const float* __rest
     const int b = blockIdx.x, tid = threadIdx.x;
     __shared__ BestD s_best[4];
     const float2* lg = reinterpret_cast<const float2*>(logits) + (size_t)b * L;
-    BestD best{-1e300, 0x7fffffff};
+    BestD best{-INFINITY, 0x7fffffff};
     for (int t = tid; t < L; t += 256) {
         const float2 l = lg[t];
         const float m = fmaxf(l.x, l.y);

@@ -9,14 +9,26 @@ backward has produced every gradient inside them so the transfers overlap the
 rest of backward.  xGMI is point-to-point (7 links per GPU), so buckets are kept
 large (default 32 MB) to stay bandwidth- rather than latency-bound.
 """
+import datetime
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
 
+# how long a collective may stay incomplete before the process group's watchdog (RCCL) or the wait itself (gloo)
+# gives up; the default of ten minutes is longer than a benchmark run
+COLLECTIVE_TIMEOUT_S = 300
+
 
 def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* when launched by torchrun."""
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (set by torchrun or by launch_local).
+
+    With the RCCL backend rank r drives GPU LOCAL_RANK: that device must exist (a clear error names how many GPUs the
+    job needs and how many the machine has) and is bound to the communicator at creation (`device_id`), so barriers
+    and the first collective never have to guess it."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1 and not _FORCE:
         return 0, 1, 0
@@ -24,11 +36,71 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", rank))
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kwargs = {"timeout": datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S)}
     if backend == "nccl":
+        have = torch.cuda.device_count()
+        need = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if local >= have:
+            raise RuntimeError("spot_amd.dist: this job needs %d GPUs on the node (one process per GPU), the machine "
+                               "has %d; rank %d has no device %d" % (need, have, rank, local))
         torch.cuda.set_device(local)
+        kwargs["device_id"] = torch.device("cuda", local)
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend)
+        dist.init_process_group(backend=backend, **kwargs)
     return rank, world, local
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_local(nproc, argv, env=None, timeout=None):
+    """Start `nproc` fresh processes of one node running `argv` (a command list), one per GPU, with RANK / LOCAL_RANK /
+    WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, and wait for them: what `torchrun --nnodes=1
+    --nproc-per-node N` does, without re-executing anything.  The caller must not have touched the GPU (children are
+    new processes, but a parent that holds a device context would share the card with rank 0).  Returns 0 when every
+    rank exited 0; otherwise the first failing rank's exit code, after ending the ranks still running (exact PIDs)."""
+    base = dict(os.environ if env is None else env)
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(nproc),
+                LOCAL_WORLD_SIZE=str(nproc))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver supports dmabuf IPC only (RCCL needs it)
+    procs = []
+    for r in range(nproc):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(list(argv), env=e))
+    import time
+    t0, rc = time.time(), 0
+    live = set(range(nproc))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write("spot_amd.dist.launch_local: rank %d exited with code %d; ending the other ranks\n"
+                                 % (r, code))
+        if rc != 0 or (timeout is not None and time.time() - t0 > timeout):
+            if rc == 0:
+                rc = 124
+                sys.stderr.write("spot_amd.dist.launch_local: time limit of %g s reached\n" % timeout)
+            for r in sorted(live):
+                procs[r].terminate()
+            for r in sorted(live):
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            live.clear()
+        else:
+            time.sleep(0.05)
+    return rc
 
 
 # SPOT_FORCE_DIST=1: run the process group, barriers and bucket collectives even with a single rank (a one-GPU
@@ -94,10 +166,26 @@ class GradBucketReducer:
         self._armed_before = False
         self._overlap = True
         self.active = self.world > 1 or active()
+        self.issued = []           # bucket indices in the order their collectives were issued this step
         if self.active:
+            self._check_layout()
             for k, t, o in params:
                 t.register_post_accumulate_grad_hook(self._hook)
             arena.add_ready_listener(self._hook)     # gradients written into .grad by the kernels themselves
+
+    def _check_layout(self):
+        """Every rank must cut the same buckets (they are a pure function of the parameter layout): a rank with a
+        different table would issue collectives of other sizes and the job would hang in the first wait."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        import zlib
+        sig = zlib.crc32(repr([(lo, hi, n) for lo, hi, n in self.buckets]).encode()) & 0x7fffffff
+        dev = self.arena.grad_flat.device if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([sig, -sig], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if int(t[0]) != sig or int(t[1]) != -sig:
+            raise RuntimeError("spot_amd.dist: rank %d cut its gradient buffer into different buckets than its peers "
+                               "(%d buckets, signature %d)" % (dist.get_rank(), len(self.buckets), sig))
 
     def arm(self):
         """Call before backward of each step.  The first armed backward of a process launches nothing early:
@@ -105,6 +193,7 @@ class GradBucketReducer:
         all buckets go out together in finish() instead."""
         self.pending = [b[2] for b in self.buckets]
         self.handles = []
+        self.issued = []
         self._seen = set()
         self._armed = True
         self._overlap = self.overlap and self._armed_before
@@ -135,6 +224,7 @@ class GradBucketReducer:
                 if main.cuda_stream != cur.cuda_stream:
                     cur.wait_stream(main)
         self.handles.append(dist.all_reduce(self.arena.grad_flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        self.issued.append(b)
         self.pending[b] = -1
 
     def finish(self):
@@ -144,8 +234,18 @@ class GradBucketReducer:
         for b, left in enumerate(self.pending):
             if left != -1:
                 self._launch(b)
-        for h in self.handles:
-            h.wait()
+        # handles are waited for in issue order, which is the same on every rank: bucket order when everything goes
+        # out here, the order in which backward completed the buckets (a property of the graph, not of timing) with
+        # early launches
+        for n, (b, h) in enumerate(zip(self.issued, self.handles)):
+            try:
+                h.wait(datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
+            except Exception as e:
+                lo, hi, _ = self.buckets[b]
+                rank = dist.get_rank() if dist.is_initialized() else 0
+                raise RuntimeError("spot_amd.dist: rank %d: all-reduce %d of %d this step (bucket %d, floats %d..%d, "
+                                   "issue order %s) did not complete: %s"
+                                   % (rank, n, len(self.handles), b, lo, hi, self.issued, e)) from e
         if self.average and self.world > 1:
             self.arena.grad_flat.mul_(1.0 / self.world)
         self._armed = False
@@ -153,8 +253,13 @@ class GradBucketReducer:
 
 def all_ranks_ok(flag_ok, device):
     """True only if every rank reports ok (keeps skip-iteration decisions rank-consistent)."""
+    return all_ranks_all([flag_ok], device)[0]
+
+
+def all_ranks_all(flags, device):
+    """Element-wise AND of a few booleans over all ranks, in one small MIN all-reduce."""
     if not active():
-        return bool(flag_ok)
-    t = torch.tensor([1 if flag_ok else 0], dtype=torch.int32, device=device)
+        return [bool(f) for f in flags]
+    t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return bool(t.item())
+    return [bool(v) for v in t.tolist()]

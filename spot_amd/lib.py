@@ -74,6 +74,7 @@ SIGNATURES = {
     "spot_batchnorm_fwd_infer_f32": [vp] * 7 + [i32, i32, i32, f32, i32, vp],
     "spot_batchnorm_bwd_f32": [vp] * 11 + [i32, i32, i32, i32, vp],
     "spot_adamw_f32": [vp, vp, vp, vp, vp, i32, vp, vp],
+    "spot_clip_grad_norm_f32": [vp, i64, f32, vp, vp, vp],
     "spot_gemm_f32": [C.POINTER(GemmDesc), vp],
     "spot_colsum_f32": [vp, i64, vp, i64, i32, vp],
     "spot_im2col_f32": [vp, vp] + [i32] * 12 + [vp],
@@ -138,6 +139,8 @@ def load():
     lib.spot_conv3x3_winograd_general_v_floats.argtypes = [i32] * 7
     lib.spot_mha_fwd_splitk_ws_floats.restype = i64
     lib.spot_mha_fwd_splitk_ws_floats.argtypes = [i32] * 4
+    lib.spot_clip_grad_norm_ws_floats.restype = i64
+    lib.spot_clip_grad_norm_ws_floats.argtypes = []
     lib.spot_deform_col2im_ws_floats.restype = i64
     lib.spot_deform_col2im_ws_floats.argtypes = [i32] * 10
     for name, args in SIGNATURES.items():

@@ -401,6 +401,22 @@ def register_side_stream(side, main):
     _SIDE_TO_MAIN[side.cuda_stream] = (side, main)
 
 
+_NORM_WS = {}
+
+
+def clip_grad_norm_(grad_flat, max_norm):
+    """torch.nn.utils.clip_grad_norm_ over a flat gradient buffer, in place; returns the norm as a device tensor [1]
+    (max_norm <= 0: the norm only)."""
+    _chk(grad_flat, name="grad_flat")
+    dev = grad_flat.device
+    if dev not in _NORM_WS:
+        _NORM_WS[dev] = torch.empty((lib.load().spot_clip_grad_norm_ws_floats() + 1,), dtype=torch.float32, device=dev)
+    ws = _NORM_WS[dev]
+    norm = torch.empty((1,), dtype=torch.float32, device=dev)
+    lib.call("spot_clip_grad_norm_f32", _p(grad_flat), grad_flat.numel(), float(max_norm), _p(norm), _p(ws), _st())
+    return norm
+
+
 def compute_streams():
     """(side, main) stream pairs the network passes have used so far."""
     return list(_SIDE_TO_MAIN.values())

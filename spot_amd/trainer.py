@@ -13,17 +13,25 @@ What changed for the hardware:
     (ltr_sparse_trainer.py:334-357 builds Python lists of per-sample tensors);
   * one host read per iteration decides "skip" (no valid pseudo label, or a
     non-finite loss), and the decision is made rank-consistent with a MIN
-    all-reduce so data-parallel ranks never diverge;
+    all-reduce so data-parallel ranks never diverge.  The read happens after the
+    student forward has been enqueued (the host never waits for the teacher); the
+    reference returns before that forward when nothing was kept (:328-332), so an
+    iteration skipped for that reason puts the student's BatchNorm running
+    statistics back to what they were before it (the forward then ran on all-zero
+    stand-in rows and its result is discarded);
+  * the Siamese variant's gradient clipping (:126-131) is one norm + scale pass over
+    the flat gradient buffer, and a non-finite norm skips the step on every rank;
   * gradients live in one flat buffer and are all-reduced in buckets that overlap
     backward (dist.py); the optimizer is created over the same parameters.
 """
+import math
 import time
 
 import torch
 
 from . import ops
 from .arena import ParamArena
-from .dist import GradBucketReducer, all_ranks_ok, world_size
+from .dist import GradBucketReducer, all_ranks_all, all_ranks_ok, world_size
 from .tensordict import TensorDict
 
 
@@ -43,6 +51,15 @@ class LTRSparseTrainer:
         self.arena = getattr(stu, "_spot_arena", None) or ParamArena(stu)
         stu._spot_arena = self.arena
         self.reducer = GradBucketReducer(self.arena)
+        # torch.nn.utils.clip_grad_norm_(student.parameters(), 25) for the Siamese variant only, as the reference keys it
+        # on the student's class name (base_sparse_trainer.py:32, ltr_sparse_trainer.py:126-131)
+        self.arch = stu.__class__.__name__
+        self.clip_grad_norm = getattr(settings, "clip_grad_norm", 25.0 if self.arch == "Ocean" else None)
+        # the student's buffers (BatchNorm running statistics and counters), with a place to keep their values of
+        # before the forward pass
+        self._buffers = [t for _, t in self.arena.f32 if not isinstance(t, torch.nn.Parameter)]
+        self._buffers += [t for _, t in self.arena.i64]
+        self._buffers_before = [torch.empty_like(t) for t in self._buffers]
         self.num_frames = 0
         self.skipped = 0
         self._prefetched = None
@@ -73,11 +90,20 @@ class LTRSparseTrainer:
         aug_label = self._middleware_ops(middle_info, pseudo_label)
         if training:
             self.arena.zero_grad()      # before the forward pass: also resets the kernels' gradient bookkeeping
+            if self._buffers:
+                torch._foreach_copy_(self._buffers_before, self._buffers)
         loss, stats, n_keep = self._sparse_training(data_sup, data_unsup, aug_label, training)
         # single host read: kept count and loss finiteness
         flags = torch.stack([n_keep.float().reshape(()), torch.isfinite(loss.detach()).float().reshape(())]).tolist()
-        ok = all_ranks_ok(flags[0] > 0 and flags[1] > 0, self.device)
-        if not ok:
+        kept, finite = all_ranks_all([flags[0] > 0, flags[1] > 0], self.device)
+        if not kept:
+            # no valid pseudo label on some rank: the reference skips before the student forward, so nothing of
+            # that forward may persist (a non-finite loss, below, is noticed after the forward there too)
+            if training and self._buffers:
+                torch._foreach_copy_(self._buffers, self._buffers_before)
+            self.skipped += 1
+            return None
+        if not finite:
             self.skipped += 1
             return None
         if training:
@@ -85,6 +111,11 @@ class LTRSparseTrainer:
             self._prefetch_pseudo_labels(i + 1, next_unsup)
             loss.backward()
             self.reducer.finish()
+            if self.clip_grad_norm:
+                norm = ops.clip_grad_norm_(self.arena.grad_flat, float(self.clip_grad_norm))
+                if not all_ranks_ok(math.isfinite(norm.item()), self.device):
+                    self.skipped += 1
+                    return None
             self.optimizer.step()
         self.num_frames += self.settings.batch_size
         return stats

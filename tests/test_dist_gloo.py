@@ -1,75 +1,57 @@
 """World-size-2 checks of the data-parallel plumbing on CPU (gloo): clip sharding, bucketed gradient
 all-reduce over the flat arena overlapped with backward, and the rank-consistent skip decision."""
 import os
-import socket
+import sys
 
-import numpy as np
 import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _model():
-    torch.manual_seed(0)
-    return torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.ReLU(), torch.nn.BatchNorm1d(64),
-                               torch.nn.Linear(64, 64), torch.nn.ReLU(), torch.nn.Linear(64, 4))
-
-
-def _worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    from spot_amd.arena import ParamArena
-    from spot_amd.dist import GradBucketReducer, all_ranks_ok, init_from_env, shard_range
-    r, w, _ = init_from_env("gloo")
-    assert (r, w) == (rank, world)
-    net = _model()
-    arena = ParamArena(net)
-    red = GradBucketReducer(arena, bucket_bytes=4096)        # several buckets
-    assert len(red.buckets) >= 2
-    x = torch.from_numpy(np.random.default_rng(10 + rank).standard_normal((8, 16)).astype(np.float32))
-    for _ in range(2):                                       # second pass checks re-arming and zeroing
-        arena.zero_grad()
-        red.arm()
-        net(x).square().sum().backward()
-        red.finish()
-    grads = {k: p.grad.clone() for k, p in net.named_parameters()}
-    # every .grad must still be a view into the flat buffer
-    for (k, t), o in zip(arena.f32, arena.offsets):
-        if isinstance(t, torch.nn.Parameter):
-            assert t.grad.data_ptr() == arena.grad_flat[o:].data_ptr(), k
-    lo, hi = shard_range(1024, rank, world)
-    ok_all = all_ranks_ok(True, "cpu")
-    ok_mixed = all_ranks_ok(rank == 0, "cpu")
-    torch.save({"grads": grads, "range": (lo, hi), "ok_all": ok_all, "ok_mixed": ok_mixed}, out % rank)
-    dist.destroy_process_group()
-
-
-def test_bucketed_grad_allreduce_world2(tmp_path):
-    world, port = 2, _free_port()
+def _run_two_ranks(tmp_path):
+    """Two ranks through the launcher bench.py uses when it is started without torchrun (spot_amd.dist.launch_local)."""
+    from spot_amd.dist import launch_local
     out = str(tmp_path / "r%d.pt")
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    res = [torch.load(out % r, weights_only=False) for r in range(world)]
-    # reference: average of the two ranks' local gradients
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    rc = launch_local(2, [sys.executable, os.path.join(ROOT, "tests", "dist_gloo_worker.py"), out], env=env, timeout=300)
+    assert rc == 0
+    return [torch.load(out % r, weights_only=False) for r in range(2)]
+
+
+def test_world2_bucketed_allreduce_and_trainer_iteration(tmp_path):
+    from tests.dist_gloo_worker import model, rank_input
+    world = 2
+    res = _run_two_ranks(tmp_path)
+    assert [r["rank"] for r in res] == [0, 1] and all(r["world"] == 2 for r in res)
+    # ---- bucketed all-reduce: the average of the two ranks' local gradients
     ref = None
     for rank in range(world):
-        net = _model()
-        x = torch.from_numpy(np.random.default_rng(10 + rank).standard_normal((8, 16)).astype(np.float32))
-        net(x).square().sum().backward()
+        net = model()
+        net(rank_input(rank)).square().sum().backward()
         g = {k: p.grad.clone() for k, p in net.named_parameters()}
         ref = g if ref is None else {k: ref[k] + g[k] for k in g}
     ref = {k: v / world for k, v in ref.items()}
     for r in range(world):
+        p1 = res[r]["part1"]
         for k, v in ref.items():
-            torch.testing.assert_close(res[r]["grads"][k], v, rtol=1e-5, atol=1e-6)
-        assert res[r]["ok_all"] is True and res[r]["ok_mixed"] is False
-    assert res[0]["range"] == (0, 512) and res[1]["range"] == (512, 1024)
+            torch.testing.assert_close(p1["grads"][k], v, rtol=1e-5, atol=1e-6)
+        assert p1["ok_all"] is True and p1["ok_mixed"] is False
+    assert res[0]["part1"]["range"] == (0, 512) and res[1]["part1"]["range"] == (512, 1024)
+    # ---- train_iteration: iteration 1 is skipped on BOTH ranks although only rank 1 had nothing to train on; the
+    # other iterations step, and the students stay bit-identical because they only ever see averaged gradients
+    for r in range(world):
+        p2 = res[r]["part2"]
+        assert [e["stepped"] for e in p2["log"]] == [True, False, True, True]
+        assert [e["changed"] for e in p2["log"]] == [True, False, True, True]
+        assert p2["skipped"] == 1
+    assert torch.equal(res[0]["part2"]["weights"], res[1]["part2"]["weights"])
+    assert not torch.equal(res[0]["part2"]["running_mean"], res[1]["part2"]["running_mean"])   # BatchNorm stays per rank
+
+
+def test_launcher_reports_a_failing_rank():
+    from spot_amd.dist import launch_local
+    code = "import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(60)"
+    assert launch_local(2, [sys.executable, "-c", code], timeout=120) == 7
 
 
 def test_shard_range_covers_everything():

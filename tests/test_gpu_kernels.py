@@ -75,6 +75,43 @@ def test_decode_random_vs_oracle(ops):
     np.testing.assert_allclose(score.cpu().numpy(), dec["best_score"].numpy(), rtol=2e-6)
 
 
+def test_decode_with_nan_scores_stays_in_range_and_filters_the_clip(ops):
+    """A diverged teacher: score maps that are NaN everywhere or in places.  torch.max returns the first NaN's index and
+    a NaN score; the clip's confidence then fails the threshold.  The kernels must do the same and never read outside
+    the clip's map."""
+    from spot_amd import lib as L_
+    B, L = 5, 1024
+    lg = det_input("lg", (B, L, 2), 8, -3, 3)
+    bx = det_input("bx", (B, L, 4), 8, 0.1, 0.9)
+    io = det_input("io", (B, L, 1), 8, 0.9, 1.0)
+    lg[0] = np.nan                                  # every score NaN -> token 0
+    lg[1, 700, 0] = np.nan
+    lg[1, 300, 1] = np.nan                          # two NaN scores -> the first one, token 300
+    io[2, :, 0] = np.nan                            # finite scores, NaN confidences -> not kept
+    lg[3, 1023] = np.nan                            # the last token only
+    ue = np.concatenate([det_input("uxy", (B, 2), 8, 0, 400), det_input("uwh", (B, 2), 8, 20, 200)], -1).astype(np.float32)
+    rf = det_input("rf", (B,), 8, 0.5, 2)
+    res = ops.decode_filter(G(lg), G(bx), G(io.reshape(B, L)), 0.40, 32, 256, 256, G(ue), G(rf), G(ue), G(rf), 256, 0.85)
+    dec = O.decode_teacher(T(lg), T(bx), T(io), 0.40, 32, 256, 256)
+    assert dec["best_idx"].tolist()[:2] == [0, 300] and dec["best_idx"].tolist()[3] == 1023
+    assert np.array_equal(res["best_idx"].cpu().numpy(), dec["best_idx"].numpy().astype(np.int32))
+    np.testing.assert_array_equal(np.isnan(res["best_score"].cpu().numpy()), [True, True, False, True, False])
+    np.testing.assert_array_equal(res["best_conf"].cpu().numpy(), dec["best_conf"].numpy())
+    np.testing.assert_array_equal(res["best_bbox"].cpu().numpy(), dec["best_bbox"].numpy())
+    flt = O.middleware_filter(dec["best_bbox"], dec["best_conf"], T(ue), T(rf), T(ue), T(rf), 256, 0.85)
+    assert res["aug_success"].cpu().numpy().astype(bool).tolist() == flt["aug_success"].tolist() == [True, True, False, True, True]
+    # the online tracker's decode: numpy.argmax picks the first NaN too
+    h = np.hanning(32)
+    window = np.outer(h, h).flatten()
+    for i in (0, 1, 3, 4):
+        best6 = torch.empty((6,), dtype=torch.float64, device=DEV)
+        lg_i, bx_i, win = G(lg[i:i + 1]), G(bx[i:i + 1]), G(window)          # named: they must outlive the launch
+        L_.call("spot_tracker_decode", ops._p(lg_i), ops._p(bx_i), ops._p(win), 0.49, ops._p(best6), None, 1, L, ops._st())
+        _, pscore, _, _, _ = O.tracker_post(lg[i], bx[i], window, 0.49, np.array([100.0, 100.0]), np.array([50.0, 50.0]), (300, 400))
+        assert int(best6[1].item()) == int(np.argmax(pscore))
+        np.testing.assert_array_equal(best6[2:].cpu().numpy(), bx[i, int(np.argmax(pscore))].astype(np.float64))
+
+
 def test_decode_ragged_L(ops):
     # token counts that are not a multiple of the workgroup size, B = 1 and B = 0
     for B, n in ((1, 5), (3, 9), (2, 20)):
@@ -113,6 +150,8 @@ def test_gather_rows(ops):
     assert torch.equal(ops.gather_rows(src, idx), src[idx.long()])
     srcf = G(det_input("srcf", (24, 3), 3, 0, 1))       # 12-byte rows: byte path
     assert torch.equal(ops.gather_rows(srcf, idx), srcf[idx.long()])
+    none = torch.full((5,), -1, dtype=torch.int32, device=DEV)      # nothing was kept: defined, all-zero rows
+    assert not ops.gather_rows(src, none).any() and not ops.gather_rows(srcf, none).any()
 
 
 def test_boxes_golden(ops, golden):

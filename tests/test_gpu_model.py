@@ -455,3 +455,51 @@ def test_student_forward_with_in_network_augmentation():
     assert not torch.equal(out["aug_anno"], anno_in)                      # pseudo-labelled pairs: boxes follow
     assert (out["aug_anno"] >= 0).all()
 
+
+
+def test_all_failed_batch_is_skipped_and_leaves_the_student_untouched():
+    """No clip passes the confidence threshold: the iteration is skipped as the reference does before its student forward
+    (ltr_sparse_trainer.py:328-332): parameters, BatchNorm running statistics and counters stay bit-identical, no
+    optimizer step happens, and the next good iteration trains normally."""
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.criterion import transt_loss
+    from spot_amd.middleware import SparseMiddleware
+    from spot_amd.trainer import LTRSparseTrainer
+    S = Settings(dropout=0.0, batch_size_sup=2, batch_size_unsup=4, teacher_update_frequency=1000)
+    S.curriculum_settings["confidence_threshold"] = 2.0            # a sigmoid output never reaches it
+    stu, tea = build(7, 0.0), build(7, 0.0)
+    actor = TranstSparseActor(S, stu, tea, transt_loss(S))
+    opt = torch.optim.AdamW([p for p in stu.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
+    trainer = LTRSparseTrainer(actor, None, opt, S, SparseMiddleware(S))
+    data_unsup, mid = unsup_batch(4, 3, device=DEV)
+    data_sup = sup_batch(2, 3, device=DEV)
+    before = {k: v.detach().clone() for k, v in stu.state_dict().items()}
+    assert trainer.train_iteration(0, data_sup, data_unsup, mid) is None and trainer.skipped == 1
+    for k, v in stu.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    trainer.middleware.confidence_threshold = 0.0
+    S.curriculum_settings["confidence_threshold"] = 0.0
+    trainer.middleware = SparseMiddleware(S)
+    stats = trainer.train_iteration(1, sup_batch(2, 3, device=DEV), data_unsup, mid)
+    assert stats is not None and torch.isfinite(stats["Loss/total"])
+    sd = stu.state_dict()
+    assert not torch.equal(sd["class_embed.layers.2.weight"], before["class_embed.layers.2.weight"])
+    assert int(sd["backbone.0.body.bn1.num_batches_tracked"]) == int(before["backbone.0.body.bn1.num_batches_tracked"]) + 2
+
+
+def test_clip_grad_norm_matches_torch():
+    from spot_amd import ops
+    g = torch.randn(1_000_448, device=DEV) * 0.05
+    for max_norm in (25.0, 1e9):
+        mine = g.clone()
+        norm = ops.clip_grad_norm_(mine, max_norm)
+        p = torch.nn.Parameter(torch.zeros_like(g))
+        p.grad = g.clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_([p], max_norm)
+        np.testing.assert_allclose(norm.item(), ref_norm.item(), rtol=1e-5)
+        np.testing.assert_allclose(mine.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+    bad = g.clone()
+    bad[12345] = float("nan")
+    kept = bad.clone()
+    assert not np.isfinite(ops.clip_grad_norm_(bad, 25.0).item())
+    assert torch.equal(torch.nan_to_num(bad), torch.nan_to_num(kept))          # untouched: the caller skips the step
