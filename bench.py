@@ -37,10 +37,13 @@ def build_world(args):
                          "bench.py --gpus %d` or under torchrun with --nproc-per-node %d"
                          % (args.gpus, world_env, args.gpus, args.gpus))
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    need = 1 if args.rehearse_on_one_gpu else args.gpus
+    if have < need:
         raise SystemExit("bench.py: --gpus %d needs %d GPUs on this node, found %d (rank %s)"
-                         % (args.gpus, args.gpus, have, os.environ.get("RANK", "0")))
-    rank, world, local = sdist.init_from_env("nccl")
+                         % (args.gpus, need, have, os.environ.get("RANK", "0")))
+    if args.rehearse_on_one_gpu:
+        os.environ["LOCAL_RANK"] = "0"          # every rank on GPU 0; RCCL refuses that, so the group runs over gloo
+    rank, world, local = sdist.init_from_env("gloo" if args.rehearse_on_one_gpu else "nccl")
     torch.cuda.set_device(local)
     return rank, world, local
 
@@ -55,8 +58,6 @@ def build_job(args, rank):
     from spot_amd.trainer import LTRSparseTrainer
     from spot_amd.transt import transt_resnet50
 
-    if os.environ.get("SPOT_CUDNN_BENCH", "0") == "1":
-        torch.backends.cudnn.benchmark = True
     # the reference's training configuration: dropout 0.1; in-network augmentation with brightness jitter 0.2,
     # grey-scale 0.05, rotation +-10 degrees, left/right flip 0.35, up/down flip 0.10 (spot_transt_003.py:45,80,85)
     S = Settings(device="cuda", dropout=args.dropout, batch_size_sup=args.sup, batch_size_unsup=args.clips)
@@ -69,20 +70,14 @@ def build_job(args, rank):
     torch.manual_seed(ops_seed)
     stu = det_fill_(transt_resnet50(S), 0).cuda()
     tea = det_fill_(transt_resnet50(S, network="teacher"), 0).cuda()
-    if os.environ.get("SPOT_CHANNELS_LAST", "0") == "1":
-        stu.backbone.to(memory_format=torch.channels_last)
-        tea.backbone.to(memory_format=torch.channels_last)
     stu._spot_arena = ParamArena(stu)
     tea._spot_arena = ParamArena(tea)
     actor = TranstSparseActor(S, stu, tea, transt_loss(S))
     lr, wd, br = (S.optimizer_parameters[k] for k in ("learning_rate", "weight_decay", "backbone_ratio"))
     groups = [{"params": [p for n, p in stu.named_parameters() if "backbone" not in n and p.requires_grad]},
               {"params": [p for n, p in stu.named_parameters() if "backbone" in n and p.requires_grad], "lr": br * lr}]
-    if os.environ.get("SPOT_TORCH_ADAMW", "0") == "1":
-        opt = torch.optim.AdamW(groups, lr=lr, weight_decay=wd)
-    else:
-        from spot_amd.optim import FlatAdamW
-        opt = FlatAdamW(groups, stu._spot_arena, lr=lr, weight_decay=wd)
+    from spot_amd.optim import FlatAdamW
+    opt = FlatAdamW(groups, stu._spot_arena, lr=lr, weight_decay=wd)
     trainer = LTRSparseTrainer(actor, None, opt, S, SparseMiddleware(S))
     data_unsup, mid = unsup_batch(args.clips, 1 + rank, device="cuda")
     data_sup = sup_batch(args.sup, 1 + rank, device="cuda")
@@ -181,7 +176,14 @@ def main():
                     help="attention-core matrix products: exact fp32 (default, the headline config) or bf16")
     ap.add_argument("--exclusive-steps", type=int, default=2,
                     help="extra untimed-for-throughput steps with the second stream off, for per-kernel durations")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="functional rehearsal of --gpus N on a machine with one GPU: all ranks share GPU 0 and the "
+                         "process group runs over gloo (RCCL refuses two ranks on one device); the line it prints says "
+                         "so and is not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="do not hand the trainer the next step's unlabelled batch (no teacher pass beside the backward)")
+    ap.add_argument("--timer-shapes", action="store_true", help="key the timed GEMM launches by problem shape as well")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--time-kernels", default="gemm_nt",
                     help="kernel classes bracketed with HIP events in the timed steps, comma separated, or 'all' "
@@ -213,7 +215,7 @@ def main():
     # every step hands the trainer the next step's unlabelled batch too (here the same resident batch), as a
     # data loader with one batch of look-ahead would
     unsup_view = TensorDict(data_unsup)
-    prefetch = os.environ.get("SPOT_PREFETCH_TEACHER", "1") == "1"
+    prefetch = not args.no_lookahead
 
     def step(i, lookahead=True):
         return trainer.train_iteration(i, TensorDict(data_sup), unsup_view, mid,
@@ -224,7 +226,7 @@ def main():
     timer = None
     if not args.no_kernel_timing:
         only = None if args.time_kernels == "all" else args.time_kernels.split(",")
-        timer = ops.TIMER = ops.KernelTimer(shapes=os.environ.get("SPOT_TIMER_SHAPES", "0") == "1", only=only)
+        timer = ops.TIMER = ops.KernelTimer(shapes=args.timer_shapes, only=only)
     skipped0 = trainer.skipped
     barrier()
     t0 = time.perf_counter()
@@ -254,7 +256,7 @@ def main():
     comm_ranks = 1
     if collective:
         comm_ranks = dist.get_world_size()
-        mine = torch.tensor([el], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([el], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
         every = [torch.zeros_like(mine) for _ in range(comm_ranks)]
         dist.all_gather(every, mine)
         per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
@@ -296,6 +298,8 @@ def main():
             "value": round(done * args.clips * world / el, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            **({"rehearsal": "all %d ranks shared GPU 0 over gloo: functional check of the multi-rank path, not a "
+                             "measurement" % world} if args.rehearse_on_one_gpu else {}),
             "dtype": "f32" if args.attention == "f32" else "f32 (bf16 attention products)", "data": "synthetic",
             "config": {"workload": "cfg2: %d clips x 3 frames per GPU per step; teacher pseudo-label + decode + "
                                    "filter + compaction + student fwd/bwd/AdamW on %d labelled + %d pseudo-labelled "

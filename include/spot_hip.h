@@ -255,10 +255,12 @@ int spot_im2col_f32(const float* x, float* cols, int B, int C, int H, int W, int
 int spot_col2im_f32(const float* dcols, float* dx, int B, int C, int H, int W, int kh, int kw, int stride, int pad,
                     int dilation_h, int dilation_w, int Kpad, int pitch, hipStream_t stream);
 
-/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet stem (ltr/models/backbone/resnet.py:113,199) on
- * `planes` = B*C maps of H x W (H even, W a multiple of 8).  winner [planes, H/2, W/2] (or null in inference)
- * records which of the nine window positions held the maximum (the first one in row-major order on ties, as
- * ATen); the backward gathers dy through it: dx[planes, H, W] is written once, no atomics. */
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet stems (ltr/models/backbone/resnet.py:113,199;
+ * ocean_backbone.py:97 on its odd 61x61 map) on `planes` = B*C maps of H x W -> Ho x Wo = ((H-1)/2+1) x ((W-1)/2+1).
+ * Maps with even H and W a multiple of 8 take a vectorised kernel (4 outputs per thread), any other size one thread per
+ * element.  winner [planes, Ho, Wo] (or null in inference) records which of the nine window positions held the maximum
+ * (the first one in row-major order on ties, as ATen); the backward gathers dy through it: dx[planes, H, W] is written
+ * once, no atomics. */
 int spot_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* winner, long planes, int H, int W,
                               hipStream_t stream);
 int spot_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* winner, float* dx, long planes, int H, int W,

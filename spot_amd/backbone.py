@@ -13,18 +13,12 @@ The nn.BatchNorm2d modules remain as parameter/buffer holders so state-dict
 keys match the reference.
 """
 import math
-import os
 
-import numpy as np
 import torch
 from torch import nn
 
 from . import lib, ops
 from .tensordict import NestedTensor
-
-
-# 1x1 convolutions through this library's GEMM (ops.conv1x1) instead of the convolution library
-OWN_CONV1X1 = os.environ.get("SPOT_OWN_CONV1X1", "1") == "1"
 
 
 class Bottleneck(nn.Module):
@@ -44,11 +38,8 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        if OWN_CONV1X1 and x.is_cuda:
-            cb = ops.conv1x1_bn_act
-        else:
-            cb = lambda t, conv, bn, relu=False, residual=None: ops.batch_norm_act(conv(t), bn, relu=relu, residual=residual)
-        if self.downsample is None and OWN_CONV1X1 and x.is_cuda:
+        cb = ops.conv1x1_bn_act
+        if self.downsample is None:
             # identity branch handed through conv1: its gradient joins conv1's input gradient in one launch
             out, residual = cb(x, self.conv1, self.bn1, relu=True, passthrough=True)
         else:

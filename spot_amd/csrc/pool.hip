@@ -84,14 +84,71 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     *reinterpret_cast<float4*>(dx + (pl * H + yy) * W + 4 * j) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// Any map size (the Siamese variant's 61x61 stem output): one thread per output / per input element, scalar accesses.
+__global__ __launch_bounds__(256) void maxpool_fwd_any_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              unsigned char* __restrict__ win, long planes, int H, int W,
+                                                              int Ho, int Wo) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * Ho * Wo) return;
+    const int ox = (int)(idx % Wo);
+    const long t = idx / Wo;
+    const int oy = (int)(t % Ho);
+    const float* xp = x + (t / Ho) * H * W;
+    float m = -INFINITY;
+    int w = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int r = 2 * oy - 1 + ky;
+        if (r < 0 || r >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int c = 2 * ox - 1 + kx;
+            if (c < 0 || c >= W) continue;
+            const float val = xp[(long)r * W + c];
+            if (val > m) {
+                m = val;
+                w = ky * 3 + kx;
+            }
+        }
+    }
+    y[idx] = m;
+    if (win) win[idx] = (unsigned char)w;
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_any_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ win,
+                                                              float* __restrict__ dx, long planes, int H, int W, int Ho,
+                                                              int Wo) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * H * W) return;
+    const int xx = (int)(idx % W);
+    const long t = idx / W;
+    const int yy = (int)(t % H);
+    const long pl = t / H;
+    float o = 0.f;
+    // pixel (yy, xx) lies in windows oy with 2oy - 1 <= yy <= 2oy + 1, i.e. oy in {yy/2, (yy+1)/2}; likewise ox
+    for (int oy = yy >> 1; oy <= (yy + 1) >> 1 && oy < Ho; ++oy)
+        for (int ox = xx >> 1; ox <= (xx + 1) >> 1 && ox < Wo; ++ox) {
+            const int ky = yy - (2 * oy - 1), kx = xx - (2 * ox - 1);
+            if (win[(pl * Ho + oy) * Wo + ox] == ky * 3 + kx) o += dy[(pl * Ho + oy) * Wo + ox];
+        }
+    dx[idx] = o;
+}
+
 }  // namespace
 
 extern "C" int spot_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* winner, long planes, int H, int W,
                                          hipStream_t stream) {
     SPOT_CHECK_ARG(x && y, "maxpool_fwd: null pointer");
-    SPOT_CHECK_ARG(planes >= 0 && H >= 2 && W >= 8 && H % 2 == 0 && W % 8 == 0, "maxpool_fwd: H=%d even, W=%d multiple of 8", H, W);
-    SPOT_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0 && ((uintptr_t)winner & 3) == 0, "maxpool_fwd: unaligned buffer");
+    SPOT_CHECK_ARG(planes >= 0 && H >= 1 && W >= 1, "maxpool_fwd: bad shape planes=%ld H=%d W=%d", planes, H, W);
     if (planes == 0) return SPOT_OK;
+    if (H % 2 != 0 || W % 8 != 0 || (((uintptr_t)x | (uintptr_t)y) & 15) != 0 || ((uintptr_t)winner & 3) != 0) {
+        const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+        const long n = planes * Ho * Wo;
+        SPOT_CHECK_ARG((n + 255) / 256 < (1L << 31), "maxpool_fwd: too large");
+        maxpool_fwd_any_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(x, y, winner, planes, H, W, Ho, Wo);
+        SPOT_CHECK_LAUNCH("maxpool_fwd(any size)");
+        return SPOT_OK;
+    }
     const long n = planes * (H / 2) * (W / 8);
     SPOT_CHECK_ARG((n + 255) / 256 < (1L << 31), "maxpool_fwd: too large");
     maxpool_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(x, y, winner, planes, H, W);
@@ -102,9 +159,16 @@ extern "C" int spot_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char
 extern "C" int spot_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* winner, float* dx, long planes, int H, int W,
                                          hipStream_t stream) {
     SPOT_CHECK_ARG(dy && winner && dx, "maxpool_bwd: null pointer");
-    SPOT_CHECK_ARG(planes >= 0 && H >= 2 && W >= 8 && H % 2 == 0 && W % 8 == 0, "maxpool_bwd: H=%d even, W=%d multiple of 8", H, W);
-    SPOT_CHECK_ARG(((uintptr_t)dx & 15) == 0, "maxpool_bwd: unaligned buffer");
+    SPOT_CHECK_ARG(planes >= 0 && H >= 1 && W >= 1, "maxpool_bwd: bad shape planes=%ld H=%d W=%d", planes, H, W);
     if (planes == 0) return SPOT_OK;
+    if (H % 2 != 0 || W % 8 != 0 || ((uintptr_t)dx & 15) != 0) {
+        const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+        const long n = planes * H * W;
+        SPOT_CHECK_ARG((n + 255) / 256 < (1L << 31), "maxpool_bwd: too large");
+        maxpool_bwd_any_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(dy, winner, dx, planes, H, W, Ho, Wo);
+        SPOT_CHECK_LAUNCH("maxpool_bwd(any size)");
+        return SPOT_OK;
+    }
     const long n = planes * H * (W / 4);
     SPOT_CHECK_ARG((n + 255) / 256 < (1L << 31), "maxpool_bwd: too large");
     maxpool_bwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(dy, winner, dx, planes, H, W);

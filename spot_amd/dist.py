@@ -32,6 +32,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1 and not _FORCE:
         return 0, 1, 0
+    # the host driver supports dmabuf IPC only; read when the first GPU call of the process initialises the runtime
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     if backend is None:
@@ -223,6 +225,12 @@ class GradBucketReducer:
                     cur.wait_stream(side)
                 if main.cuda_stream != cur.cuda_stream:
                     cur.wait_stream(main)
+            # RCCL's collective is a kernel ordered behind that stream.  Any other backend (gloo) moves device tensors
+            # through the host from worker threads that synchronise private streams; issued while this process still
+            # has compute queued, those waits were observed never to return (two ranks sharing one GPU; the same
+            # collectives on an idle device complete), so the device is drained first.  Not the product path.
+            if dist.is_initialized() and dist.get_backend() != "nccl":
+                torch.cuda.synchronize()
         self.handles.append(dist.all_reduce(self.arena.grad_flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         self.issued.append(b)
         self.pending[b] = -1

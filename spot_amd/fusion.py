@@ -15,7 +15,6 @@ from a seed (ops.manual_seed); the random stream differs from torch's, the distr
 """
 import math
 
-import os
 
 import torch
 from torch import nn
@@ -67,7 +66,7 @@ class _AttentionParams(nn.Module):
 
 
 # Run the template stream of every fusion layer on a second HIP stream (see _forward_two_streams).
-TWO_STREAMS = os.environ.get("SPOT_TWO_STREAMS", "1") == "1"
+TWO_STREAMS = True
 _SIDE_STREAMS = {}
 if TWO_STREAMS and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
     # parameters of the template stream receive their gradients on the second stream by design

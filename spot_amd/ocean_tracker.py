@@ -2,7 +2,6 @@
 frame is cut, padded and resized on the device, normalised by the preprocess kernel, run through Ocean.track, and
 reduced to the winning cell by one kernel; eight float64 values come back to the host per frame, where the
 reference's scalar box update follows."""
-import os
 import time
 import warnings
 
@@ -30,14 +29,14 @@ class Ocean_Tracker(object):
     def __init__(self, name, net, use_graph=None):
         """use_graph: replay a frame's device work (normalise, network, decode) as one captured HIP graph from the
         third frame of a sequence on.  Default: on for this package's Ocean model (whose track() is a pure device
-        function of the crop and the cached template features) unless SPOT_TRACKER_GRAPH=0; off for any other net."""
+        function of the crop and the cached template features); off for any other net."""
         self.name, self.net = name, net
         self.p = OceanConfig()
         self.state = None
         self.mean, self.std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
         if use_graph is None:
             from .ocean_model import Ocean
-            use_graph = os.environ.get("SPOT_TRACKER_GRAPH", "1") == "1" and isinstance(net, Ocean)
+            use_graph = isinstance(net, Ocean)
         self.use_graph = bool(use_graph)
         self._graph, self._eager_frames = None, 0
         self._target_dev = None
@@ -88,6 +87,7 @@ class Ocean_Tracker(object):
         s_z = round(np.sqrt(wc_z * hc_z))
         avg_chans = (image.float().mean(dim=(0, 1)).cpu().numpy() if torch.is_tensor(image) else np.mean(image, axis=(0, 1)))
         z_crop = self.get_subwindow_tracking(image, target_pos, p.exemplar_size, s_z, avg_chans)
+        self._frame = None              # the uploaded copy serves this call only: the caller may reuse its buffer
         if isinstance(self.net, torch.nn.Module):
             ops.frozen_weights.forget(self.net)     # the network may have been trained since the last sequence
         with torch.no_grad(), ops.frozen_weights():     # transformed convolution weights are kept across frames
@@ -180,6 +180,7 @@ class Ocean_Tracker(object):
         pad = d_search / scale_z
         s_x = s_z + 2 * pad
         x_crop = self.get_subwindow_tracking(image, target_pos, p.instance_size, self.python2round(s_x), avg_chans)
+        self._frame = None
         target_pos, target_sz, cls_score = self.update(net, self._normalize(x_crop), target_pos, target_sz * scale_z,
                                                        window, scale_z, p)
         target_pos[0] = max(0, min(state["im_w"], target_pos[0]))

@@ -7,7 +7,6 @@ transt.py) read like the reference's nn.Modules.
 """
 import ctypes as C
 import math
-import os
 
 import torch
 
@@ -440,7 +439,7 @@ def _join_after_backward():
 # ---------------------------------------------------------------------------
 # dense contractions
 # ---------------------------------------------------------------------------
-_GEMM_TILE = int(os.environ.get("SPOT_GEMM_TILE", "0"))   # 0: the library picks per problem; 64 / 128 force one
+_GEMM_TILE = 0   # workgroup tile handed to the library: 0 = it picks per problem; 64 / 128 force one (same results)
 
 
 def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None, ldc=None, batch=1,
@@ -525,7 +524,7 @@ def linear_dgrad(dy2, W, mask=None, out=None, accumulate=False, residual=None, a
     return out
 
 
-_SPLITK_TARGET = int(os.environ.get("SPOT_SPLITK_TARGET", "512"))
+_SPLITK_TARGET = 512
 
 
 def _splitk_for(rows_out, cols_out, k):
@@ -763,14 +762,14 @@ def conv1x1(x, conv, passthrough=False):
     if conv.stride != (1, 1):
         assert not passthrough
         x = x[:, :, ::conv.stride[0], ::conv.stride[1]]
-    if x.shape[2] * x.shape[3] % 32 != 0:       # the batch-summed weight gradient walks K in whole 32-wide tiles per clip
-        y = torch.nn.functional.conv2d(x, conv.weight, None)
+    if x.shape[2] * x.shape[3] % 32 != 0:       # the batch-summed weight gradient walks K in whole 32-wide tiles per clip:
+        y = ConvIm2colFn.apply(x, conv.weight, 1, 0, (1, 1), None)      # other maps go through a copy at a padded pitch
         return (y, x) if passthrough else y
     return Conv1x1Fn.apply(x, conv.weight, passthrough)
 
 
 def conv1x1_bn_act(x, conv, bn, relu=False, residual=None, passthrough=False):
-    """[relu](bn(conv(x)) [+ residual]) for a bias-free 1x1 convolution.  With `bn` in inference mode (and no
+    """[relu](bn(conv x) [+ residual]) for a bias-free 1x1 convolution.  With `bn` in inference mode (and no
     gradient wanted) the normalisation is a per-output-channel affine map and rides in the GEMM's epilogue together
     with the residual add and the ReLU: one launch, the map is written once.  Otherwise conv1x1 -> batch_norm_act.
     passthrough=True returns (result, x') with x' = x for the block's identity branch (see Conv1x1Fn)."""
@@ -1040,7 +1039,7 @@ class Conv3x3GenFn(_Fn):
 
 def _winograd_general_applies(x, conv):
     s, p, d = conv.stride, conv.padding, conv.dilation
-    return (WINOGRAD_GENERAL and x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (3, 3) and conv.groups == 1
+    return (x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (3, 3) and conv.groups == 1
             and s == (1, 1) and isinstance(p, tuple) and p[0] == p[1] and conv.padding_mode == "zeros"
             and d[0] in (1, 2) and d[1] in (1, 2) and (p[0] == 0 or (d[0] == d[1] and p[0] in (d[0], 2 * d[0])))
             and x.shape[2] + 2 * p[0] > 2 * d[0] and x.shape[3] + 2 * p[0] > 2 * d[1]
@@ -1048,7 +1047,7 @@ def _winograd_general_applies(x, conv):
 
 
 def conv_bn_act(x, conv, bn, relu=False):
-    """[relu](bn(conv(x))) for any nn.Conv2d this library runs.  With `bn` in inference mode and no gradient wanted, a
+    """[relu](bn(conv x)) for any nn.Conv2d this library runs.  With `bn` in inference mode and no gradient wanted, a
     3x3 convolution on the any-size Winograd path takes the normalisation (and ReLU) in its output transform, and
     keeps its transformed weights inside `with frozen_weights():`; otherwise conv_general -> batch_norm_act."""
     fold = (x.shape[0] > 0 and not bn.training and bn.track_running_stats and not torch.is_grad_enabled()
@@ -1081,27 +1080,25 @@ def conv_bn_act(x, conv, bn, relu=False):
     return y
 
 
-WINOGRAD_GENERAL = os.environ.get("SPOT_WINOGRAD_GENERAL", "1") == "1"
-OWN_CONV_IM2COL = os.environ.get("SPOT_OWN_CONV_IM2COL", "1") == "1"
-
-
 def conv_general(x, conv):
-    """nn.Conv2d `conv` applied to x: the general-size Winograd path for 3x3 / stride 1 / undilated convolutions with
-    at least 16 channels on both sides, patch matrix + GEMM for the rest of what has one group, square stride and
-    padding and zero padding mode, the module itself otherwise."""
+    """nn.Conv2d `conv` applied to x: the general-size Winograd path for 3x3 / stride 1 convolutions with at least 16
+    channels on both sides, patch matrix + GEMM for the rest of what has one group, square stride and padding and zero
+    padding mode.  Anything else is not a convolution of this hot path and raises."""
     s, p, d = conv.stride, conv.padding, conv.dilation
-    if x.shape[0] == 0:                 # an empty batch: nothing to launch, the module shapes the empty result
-        return conv(x)
-    if (OWN_CONV_IM2COL and x.is_cuda and conv.groups == 1 and s[0] == s[1] and isinstance(p, tuple) and p[0] == p[1]
-            and conv.padding_mode == "zeros" and x.dtype == torch.float32):
-        kh, kw = conv.kernel_size
-        if _winograd_general_applies(x, conv):
-            return Conv3x3GenFn.apply(x, conv.weight, conv.bias, p[0] // d[0], (d[0], d[1]))
-        Ho = (x.shape[2] + 2 * p[0] - d[0] * (kh - 1) - 1) // s[0] + 1
-        Wo = (x.shape[3] + 2 * p[0] - d[1] * (kw - 1) - 1) // s[0] + 1
-        if Ho > 0 and Wo > 0:
-            return ConvIm2colFn.apply(x, conv.weight, s[0], p[0], (d[0], d[1]), conv.bias)
-    return conv(x)
+    _chk(x, name="convolution input") if x.is_contiguous() else _chk(x.contiguous(), name="convolution input")
+    if not (conv.groups == 1 and s[0] == s[1] and isinstance(p, tuple) and p[0] == p[1] and conv.padding_mode == "zeros"):
+        raise RuntimeError("spot_amd: unsupported convolution %r (one group, square stride / padding, zero padding only)"
+                           % (conv,))
+    kh, kw = conv.kernel_size
+    Ho = (x.shape[2] + 2 * p[0] - d[0] * (kh - 1) - 1) // s[0] + 1
+    Wo = (x.shape[3] + 2 * p[0] - d[1] * (kw - 1) - 1) // s[0] + 1
+    if Ho <= 0 or Wo <= 0:
+        raise RuntimeError("spot_amd: convolution %r has no output on a %dx%d map" % (conv, x.shape[2], x.shape[3]))
+    if x.shape[0] == 0:                 # an empty batch: nothing to launch
+        return x.new_zeros((0, conv.weight.shape[0], Ho, Wo))
+    if _winograd_general_applies(x, conv):
+        return Conv3x3GenFn.apply(x, conv.weight, conv.bias, p[0] // d[0], (d[0], d[1]))
+    return ConvIm2colFn.apply(x, conv.weight, s[0], p[0], (d[0], d[1]), conv.bias)
 
 
 class MaxPool3x3s2Fn(_Fn):
@@ -1112,8 +1109,9 @@ class MaxPool3x3s2Fn(_Fn):
     def forward(ctx, x):
         x = _chk(x.contiguous())
         B, Cn, H, W = x.shape
-        y = torch.empty((B, Cn, H // 2, W // 2), dtype=torch.float32, device=x.device)
-        win = torch.empty((B, Cn, H // 2, W // 2), dtype=torch.uint8, device=x.device) if _wants(ctx, 0) else None
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((B, Cn, Ho, Wo), dtype=torch.float32, device=x.device)
+        win = torch.empty((B, Cn, Ho, Wo), dtype=torch.uint8, device=x.device) if _wants(ctx, 0) else None
         lib.call("spot_maxpool3x3s2_fwd_f32", _p(x), _p(y), _p(win), B * Cn, H, W, _st())
         ctx.save_for_backward(win)
         ctx.shape = (B, Cn, H, W)
@@ -1129,16 +1127,17 @@ class MaxPool3x3s2Fn(_Fn):
 
 
 def max_pool_3x3_s2(x, pool):
-    """nn.MaxPool2d `pool` applied to x: this library's kernel for the stem's 3x3 / stride 2 / padding 1 pool on
-    maps with even height and a width that is a multiple of 8, the module itself otherwise."""
+    """nn.MaxPool2d `pool` applied to x: this library's kernels for the stems' 3x3 / stride 2 / padding 1 pool; other
+    pools are not part of this hot path and raise."""
     ks = pool.kernel_size if isinstance(pool.kernel_size, tuple) else (pool.kernel_size,) * 2
     st = pool.stride if isinstance(pool.stride, tuple) else (pool.stride,) * 2
     pd = pool.padding if isinstance(pool.padding, tuple) else (pool.padding,) * 2
     dl = pool.dilation if isinstance(pool.dilation, tuple) else (pool.dilation,) * 2
     if (x.is_cuda and ks == (3, 3) and st == (2, 2) and pd == (1, 1) and dl == (1, 1) and not pool.ceil_mode
-            and not pool.return_indices and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0 and x.dtype == torch.float32):
+            and not pool.return_indices and x.dtype == torch.float32):
         return MaxPool3x3s2Fn.apply(x)
-    return pool(x)
+    raise RuntimeError("spot_amd: unsupported max-pool %r on a %s %s map (3x3 / stride 2 / padding 1 on float32 GPU maps "
+                       "only)" % (pool, tuple(x.shape), x.dtype))
 
 
 # ---------------------------------------------------------------------------
@@ -1177,12 +1176,12 @@ def _winograd(inp, weight, Cout, flip, dilation=1, keep_v=False, bn=None, relu=F
 class Conv3x3Fn(_Fn):
     """Bias-free 3x3 convolution, stride 1, padding 1 (resnet.py:79-81): forward and input gradient by the
     Winograd F(4x4, 3x3) path of the library; the weight gradient likewise (summed in the transformed domain and
-    added straight into the flat gradient buffer), or by the convolution library with SPOT_WINOGRAD_WGRAD=0."""
+    added straight into the flat gradient buffer)."""
 
     @staticmethod
     def forward(ctx, x, weight, dilation=1):
         x = _chk(x.contiguous())
-        keep = _wants(ctx, 1) and _WINOGRAD_WGRAD        # the transformed input serves the weight gradient too
+        keep = _wants(ctx, 1)                            # the transformed input serves the weight gradient too
         y = _winograd(x, weight, weight.shape[0], False, dilation, keep_v=keep)
         y, v = y if keep else (y, None)
         ctx.save_for_backward(None if keep else x, weight, v)
@@ -1201,10 +1200,7 @@ class Conv3x3Fn(_Fn):
         dil = ctx.dilation
         dx = _winograd(dy, weight, weight.shape[1], True, dil) if ctx.needs_input_grad[0] else None
         dw = None
-        if ctx.needs_input_grad[1] and not _WINOGRAD_WGRAD:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (dil, dil), (dil, dil), False, (0, 0), 1,
-                                                     (False, True, False))[1]
-        elif ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1]:
             B, Cin, H, W = ctx.xshape
             Cout = weight.shape[0]
             sk = _sink(pw)
@@ -1219,36 +1215,25 @@ class Conv3x3Fn(_Fn):
         return dx, dw, None
 
 
-_WINOGRAD_WGRAD = os.environ.get("SPOT_WINOGRAD_WGRAD", "1") == "1"
-
-
-# batches with fewer 4x4 tiles than this go to the convolution library instead (-1: always).  Measured on the
-# tracker's single frame (64 tiles on layer3) the Winograd path is as fast as the library's, so the default is 0.
-_WINOGRAD_MIN_TILES = int(os.environ.get("SPOT_WINOGRAD_MIN_TILES", "0"))
-
-
 def conv3x3(x, conv):
     """nn.Conv2d `conv` applied to x: the Winograd path for bias-free 3x3 / stride 1 convolutions with dilation d = 1
-    or 2 and padding d on maps whose sides are multiples of 4d; strided ones go to conv_general; what is left
-    (stride-1 convolutions on batches too small for the transformed GEMMs) to the convolution library."""
+    or 2 and padding d on maps whose sides are multiples of 4d; everything else goes to conv_general (any-size
+    Winograd, or patch matrix + GEMM for strided ones)."""
     if winograd_applies(x, conv):
         return Conv3x3Fn.apply(x, conv.weight, conv.dilation[0])
-    if conv.stride != (1, 1):
-        return conv_general(x, conv)
-    return conv(x)
+    return conv_general(x, conv)
 
 
 def winograd_applies(x, conv):
     B, _, H, W = x.shape
     d = conv.dilation[0]
-    return (_WINOGRAD_MIN_TILES >= 0 and x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+    return (x.is_cuda and B > 0 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and d in (1, 2) and conv.dilation == (d, d) and conv.padding == (d, d) and conv.groups == 1
-            and conv.bias is None and H % (4 * d) == 0 and W % (4 * d) == 0
-            and B * (H // 4) * (W // 4) >= _WINOGRAD_MIN_TILES)
+            and conv.bias is None and H % (4 * d) == 0 and W % (4 * d) == 0)
 
 
 def conv3x3_bn_act(x, conv, bn, relu=False):
-    """[relu](bn(conv(x))) for the bottleneck's 3x3 convolution.  With `bn` in inference mode and no gradient wanted
+    """[relu](bn(conv x)) for the bottleneck's 3x3 convolution.  With `bn` in inference mode and no gradient wanted
     the normalisation and the ReLU ride in the Winograd output transform; otherwise conv3x3 -> batch_norm_act."""
     if (not bn.training and bn.track_running_stats and not torch.is_grad_enabled() and winograd_applies(x, conv)):
         return _winograd(_chk(x.contiguous()), conv.weight, conv.weight.shape[0], False, conv.dilation[0], bn=bn, relu=relu)
@@ -1389,15 +1374,10 @@ def batch_norm_act(x, bn, relu=False, residual=None):
 # ---------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------
-_MHA_SPLITK = os.environ.get("SPOT_MHA_SPLITK", "1") == "1"
-
-
 def _mha_key_splits(B, Lq, Lk, nhead):
     """Key ranges per query tile for an inference forward whose grid of (query tile, head, clip) workgroups would
     leave most of the 256 CUs idle (the online tracker: one clip): enough ranges of whole 64-key tiles to reach a few
     hundred workgroups, at most 8."""
-    if not _MHA_SPLITK:
-        return 1
     wgs = (Lq + 127) // 128 * nhead * B
     if wgs >= 128:
         return 1

@@ -5,22 +5,19 @@ pysot_toolkit/trackers/net_wrappers.py:4-56.
 ``initialize(image, {'init_bbox': [x,y,w,h]}) -> {'time'}`` and
 ``track(image) -> {'target_bbox': [x,y,w,h], 'best_score': pscore}``.
 
-Per frame: the crop is cut on the host (numpy, as the reference), uploaded as
-uint8 (a quarter of the reference's float32 upload), normalised by the
-preprocess kernel, pushed through backbone + fusion + heads, and the 1024-token
-score map is reduced on the device; one small buffer (the chosen box and the
-pscore map the reference also returns) comes back per frame.  cv2 is not
-available here: when the crop must be rescaled, a bilinear resize on the GPU
-stands in for cv2.resize (outside the parity contract, which is stated at the
-network boundary).
+Per frame: the frame is uploaded once as uint8 HWC; one kernel cuts the window,
+pads it with the channel average and resizes it (OpenCV's 8-bit INTER_LINEAR
+arithmetic); the crop is normalised by the preprocess kernel, pushed through
+backbone + fusion + heads, and the 1024-token score map is reduced on the device;
+one small buffer (the chosen box and the pscore map the reference also returns)
+comes back per frame.  From the third frame of a sequence the device work
+replays as one captured HIP graph.
 """
 import math
-import os
 import time
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import lib, ops
 
@@ -66,9 +63,6 @@ class NetWithBackbone:
             return self.net.track(x)
 
 
-GPU_CROP = os.environ.get("SPOT_GPU_CROP", "1") == "1"
-
-
 class TransT_Tracker(object):
     def __init__(self, name, net, window_penalty=0.49, exemplar_size=128, instance_size=256, use_graph=None):
         self.name = name
@@ -81,12 +75,12 @@ class TransT_Tracker(object):
         # A frame is ~250 kernel launches at batch 1 that keep the GPU busy for 3.2 ms, while enqueueing them from
         # Python takes 8 ms: the eager frame is host-bound.  From the third frame of a sequence on, the whole device
         # pipeline (normalise, backbone, fusion, heads, decode) therefore replays as one captured HIP graph (frames
-        # 1-2 run eagerly and warm the convolution library's algorithm choice): 8.2 -> 6.5 ms per frame on MI355X.
-        # use_graph=False or SPOT_TRACKER_GRAPH=0 keeps every frame eager.  A replayed graph repeats exactly the
+        # 1-2 run eagerly): 8.2 -> 2.3 ms per frame on MI355X.
+        # use_graph=False keeps every frame eager.  A replayed graph repeats exactly the
         # device work of the captured frame, so by default only this package's own network holder is trusted to be
         # a pure device function of the crop; any other `net` object runs eagerly unless use_graph=True is passed.
         if use_graph is None:
-            use_graph = os.environ.get("SPOT_TRACKER_GRAPH", "1") == "1" and isinstance(net, NetWithBackbone)
+            use_graph = isinstance(net, NetWithBackbone)
         self.use_graph = bool(use_graph)
         self._graph = None
         self._eager_frames = 0
@@ -102,50 +96,19 @@ class TransT_Tracker(object):
         """Square crop of side original_sz around pos, padded with the channel average and resized to model_sz
         (transt_tracker.py:41-101); returned as a uint8 [1,3,model_sz,model_sz] device tensor.  The window is cut,
         padded and resized by one kernel from the frame in device memory (`im` may already be a uint8 HWC CUDA
-        tensor; a numpy frame is uploaded once per frame); SPOT_GPU_CROP=0 cuts and pads on the host instead and
-        resizes with the framework's bilinear filter."""
+        tensor; a numpy frame is uploaded once per call of initialize / track)."""
         if isinstance(pos, float):
             pos = [pos, pos]
         sz = int(original_sz)
         c = (original_sz + 1) / 2
         context_xmin = np.floor(pos[0] - c + 0.5)
         context_ymin = np.floor(pos[1] - c + 0.5)
-        if GPU_CROP or torch.is_tensor(im):
-            pad = np.asarray(avg_chans, dtype=np.float64).astype(np.uint8)        # numpy's cast on assignment
-            return ops.crop_resize_u8(self._device_frame(im), int(context_xmin), int(context_ymin), sz, int(model_sz), pad)
-        im_sz = im.shape
-        context_xmax = context_xmin + sz - 1
-        context_ymax = context_ymin + sz - 1
-        left_pad = int(max(0., -context_xmin))
-        top_pad = int(max(0., -context_ymin))
-        right_pad = int(max(0., context_xmax - im_sz[1] + 1))
-        bottom_pad = int(max(0., context_ymax - im_sz[0] + 1))
-        context_xmin, context_xmax = context_xmin + left_pad, context_xmax + left_pad
-        context_ymin, context_ymax = context_ymin + top_pad, context_ymax + top_pad
-        r, c_, k = im.shape
-        if any([top_pad, bottom_pad, left_pad, right_pad]):
-            te_im = np.zeros((r + top_pad + bottom_pad, c_ + left_pad + right_pad, k), np.uint8)
-            te_im[top_pad:top_pad + r, left_pad:left_pad + c_, :] = im
-            if top_pad:
-                te_im[0:top_pad, left_pad:left_pad + c_, :] = avg_chans
-            if bottom_pad:
-                te_im[r + top_pad:, left_pad:left_pad + c_, :] = avg_chans
-            if left_pad:
-                te_im[:, 0:left_pad, :] = avg_chans
-            if right_pad:
-                te_im[:, c_ + left_pad:, :] = avg_chans
-            patch = te_im[int(context_ymin):int(context_ymax + 1), int(context_xmin):int(context_xmax + 1), :]
-        else:
-            patch = im[int(context_ymin):int(context_ymax + 1), int(context_xmin):int(context_xmax + 1), :]
-        t = torch.from_numpy(np.ascontiguousarray(patch.transpose(2, 0, 1)[np.newaxis])).cuda(non_blocking=True)
-        if model_sz != original_sz:
-            t = F.interpolate(t.float(), size=(model_sz, model_sz), mode="bilinear", align_corners=False)
-            t = t.round().clamp(0, 255).to(torch.uint8)
-        return t.contiguous()
+        pad = np.asarray(avg_chans, dtype=np.float64).astype(np.uint8)        # numpy's cast on assignment
+        return ops.crop_resize_u8(self._device_frame(im), int(context_xmin), int(context_ymin), sz, int(model_sz), pad)
 
     def _device_frame(self, im):
-        """The frame as a uint8 HWC device tensor; a host frame is uploaded once and remembered while it is the
-        current one (initialize and track both cut from it)."""
+        """The frame as a uint8 HWC device tensor.  A host frame is uploaded once per initialize() / track() call
+        (both drop the copy when they return: a caller may refill the same numpy buffer with the next frame)."""
         if torch.is_tensor(im):
             return im if im.is_cuda else im.cuda()
         held = getattr(self, "_frame", None)
@@ -180,6 +143,7 @@ class TransT_Tracker(object):
                                 else np.mean(image, axis=(0, 1)))
         z_crop = self.get_subwindow(image, self.center_pos, self.exemplar_size, s_z, self.channel_average)
         self.net.template(self._normalize(z_crop))
+        self._frame = None
         self._graph, self._eager_frames = None, 0       # the captured graph reads the previous template's features
         return {"time": time.time() - tic}
 
@@ -210,8 +174,7 @@ class TransT_Tracker(object):
             two = fusion.TWO_STREAMS
             try:
                 # the template stream of the fusion layers forks from and rejoins the capture stream, so the replayed
-                # graph keeps the two branches concurrent (SPOT_GRAPH_TWO_STREAMS=0: one stream inside the graph)
-                fusion.TWO_STREAMS = two and os.environ.get("SPOT_GRAPH_TWO_STREAMS", "1") == "1"
+                # graph keeps the two branches concurrent
                 self._x_static = x_crop.clone()
                 # one eager pass on the capture stream first: library handles and code objects that are created
                 # per stream on first use must exist before capture begins
@@ -241,6 +204,7 @@ class TransT_Tracker(object):
         h_x = self.size[1] + (4 - 1) * ((self.size[0] + self.size[1]) * 0.5)
         s_x = math.ceil(math.sqrt(w_x * h_x))
         x_crop = self.get_subwindow(image, self.center_pos, self.instance_size, round(s_x), self.channel_average)
+        self._frame = None
         res = self._run_frame(x_crop).cpu().numpy()            # the frame's one device->host read
         bx, by, bw, bh = res[2:6]
         pscore = res[6:]

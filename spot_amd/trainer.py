@@ -31,7 +31,7 @@ import torch
 
 from . import ops
 from .arena import ParamArena
-from .dist import GradBucketReducer, all_ranks_all, all_ranks_ok, world_size
+from .dist import GradBucketReducer, all_ranks_all, all_ranks_ok
 from .tensordict import TensorDict
 
 

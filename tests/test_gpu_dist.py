@@ -122,3 +122,25 @@ def test_rccl_single_rank_bucket_allreduce_is_identity(monkeypatch):
             assert len(nb) > 0
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_starts_its_own_ranks_two_rank_rehearsal(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the parent starts two fresh rank processes (spot_amd.dist.
+    launch_local), they form a group, run the step with the gradient buckets all-reduced between them, agree on the
+    slowest rank's time and rank 0 prints one line.  On a one-GPU box both ranks share GPU 0 over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup",
+           "1", "--no-cpu-baseline", "--exclusive-steps", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["communicator_ranks"] == 2
+    assert len(line["config"]["ms_per_step_per_rank"]) == 2 and line["value"] > 0
+    assert line["ms_per_step"] >= max(line["config"]["ms_per_step_per_rank"]) - 1e-6

@@ -681,10 +681,9 @@ def test_conv1x1_as_gemm_vs_torch(ops, B, Ci, Co, H, W, stride):
 
 @pytest.mark.parametrize("B,Ci,Co,H,W,dil", [(2, 8, 12, 8, 12, 1), (3, 64, 64, 16, 16, 1), (1, 5, 3, 4, 4, 1),
                                              (2, 128, 96, 32, 32, 1), (2, 8, 12, 8, 16, 2), (3, 64, 48, 32, 32, 2)])
-def test_conv3x3_winograd_vs_direct(ops, monkeypatch, B, Ci, Co, H, W, dil):
+def test_conv3x3_winograd_vs_direct(ops, B, Ci, Co, H, W, dil):
     """Forward, input gradient (Winograd) and weight gradient against torch's direct convolution in float64."""
     import torch.nn.functional as F
-    monkeypatch.setattr(ops, "_WINOGRAD_MIN_TILES", 0)
     x = det_input("x", (B, Ci, H, W), 1, -1, 1)
     w = det_input("w", (Co, Ci, 3, 3), 2, -0.2, 0.2)
     dy = det_input("dy", (B, Co, H, W), 3, -1, 1)
@@ -742,15 +741,17 @@ def test_conv1x1_with_folded_inference_batchnorm(ops, stride, with_res):
     assert yt.requires_grad
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 3, 8, 16), (3, 64, 128, 128), (1, 5, 6, 8)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 3, 8, 16), (3, 64, 128, 128), (1, 5, 6, 8), (2, 16, 61, 61), (1, 3, 7, 12),
+                                     (2, 2, 1, 5), (1, 4, 10, 9)])
 def test_maxpool3x3s2_vs_torch(ops, B, C, H, W):
-    """Stem max-pool: values, tie-breaking and gradient equal nn.MaxPool2d(3, 2, 1) exactly."""
+    """Stem max-pool: values, tie-breaking and gradient equal nn.MaxPool2d(3, 2, 1) exactly, on the vectorised kernel's
+    shapes and on odd / small maps (the Siamese variant's 61x61)."""
     pool = torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
     x = det_input("x", (B, C, H, W), 1, -1, 1)
     xt = T(x).clone()
     xt[:, :, ::3, ::2] = 0.25                      # plateaus: ties inside many windows
     xt[0, 0, :4, :8] = -3.0                        # a constant block at the padded corner
-    dy = det_input("dy", (B, C, H // 2, W // 2), 2, -1, 1)
+    dy = det_input("dy", (B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), 2, -1, 1)
     xg = xt.to(DEV).requires_grad_()
     y = ops.max_pool_3x3_s2(xg, pool)
     assert type(y.grad_fn).__name__.startswith("MaxPool3x3s2Fn")
