@@ -434,6 +434,259 @@ bool launch_tile(const Branch* b, const float* weight, float* out, int planes, h
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Row-strip forward for the (5x5, 3x5, 5x3) triple (NB = 3) or a single 5x5 template (NB = 1).
+//
+// What the counters say about the column walk above at 384^2 / B = 128: HBM traffic is the algorithmic 1.0 GB, but
+// every wave issues ~720 vector-ALU and ~150 4-byte LDS instructions per plane, a third of the LDS cycles are bank
+// conflicts, and the vector ALU alone is busy for half of the kernel's time.  This kernel cuts both:
+//   * a work item is 8 consecutive outputs of one row.  Its inputs are row segments of 12 floats, read as three
+//     16-byte LDS loads (256 B/clk instead of 128 B/clk for 4-byte reads).  The planes are re-pitched on the way into
+//     LDS (pitch = 4 * odd number of floats) and consecutive lanes take consecutive rows, so the 16 lanes the LDS
+//     serves per cycle hit 16 distinct bank quads: no conflicts.
+//   * the products are packed: v_pk_fma_f32 on register pairs as they come out of the loads.  Taps at an even column
+//     offset v update the output pairs (0,1)(2,3)(4,5)(6,7) from input pairs (v,v+1)(v+2,v+3)...; taps at an odd v update
+//     the shifted pairs (-1,0)(1,2)...(7,8) from input pairs (v-1,v)(v+1,v+2)...: both are aligned pairs, no moves.
+//     The two partial sums are added once per branch.  55 taps cost 241 packed instead of 440 scalar multiply-adds.
+//   * re-pitching costs no index arithmetic: a thread loads the 16 bytes at (row r, quad q) of the plane in global memory
+//     (4-byte aligned; the last quad of a row runs into the next row, whose values land in the pitch padding) and
+//     stores them with one 16-byte LDS write; its (r, q) slots are fixed for the whole launch.
+// Persistent workgroups with the next plane's loads in flight in registers, as above.
+// ---------------------------------------------------------------------------
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+
+// acc += x * (tap, tap): the tap is one half of a scalar register pair that holds two consecutive taps, picked by the
+// instruction's half selectors (written as assembly because the compiler otherwise duplicates every tap into a pair of
+// its own: 110 scalar registers for the 55 taps, spilled)
+__device__ __forceinline__ void pk_fma_tap_lo(f2v& acc, f2v x, f2v taps) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "s"(taps));
+}
+__device__ __forceinline__ void pk_fma_tap_hi(f2v& acc, f2v x, f2v taps) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(x), "s"(taps));
+}
+
+// the NT taps of one plane and branch as pairs (workgroup-uniform: scalar loads)
+template <int NT>
+__device__ __forceinline__ void load_taps(const float* __restrict__ z, f2v (&zt)[(NT + 1) / 2]) {
+#pragma unroll
+    for (int m = 0; m < NT / 2; ++m) zt[m] = f2v{z[2 * m], z[2 * m + 1]};
+    if (NT & 1) zt[NT / 2] = f2v{z[NT - 1], 0.f};
+}
+
+// r[0..8) = the 8 outputs at (row, j0 .. j0+7) of the correlation of the pitched LDS plane xs with the HZ x WZ taps
+template <int HZ, int WZ, int PITCH>
+__device__ __forceinline__ void row_strip(const float* xs, const f2v (&zt)[(HZ * WZ + 1) / 2], int row, int j0, float (&r)[8]) {
+    f2v A[4], B[5];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) A[c] = f2v{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 5; ++c) B[c] = f2v{0.f, 0.f};
+    const float* base = xs + row * PITCH + j0;
+#pragma unroll
+    for (int u = 0; u < HZ; ++u) {
+        f4v x[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) x[q] = *reinterpret_cast<const f4v*>(base + u * PITCH + 4 * q);
+        const f2v xp[6] = {x[0].xy, x[0].zw, x[1].xy, x[1].zw, x[2].xy, x[2].zw};
+#pragma unroll
+        for (int v = 0; v < WZ; ++v) {
+            const int t = u * WZ + v;
+            if ((v & 1) == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (t & 1) pk_fma_tap_hi(A[c], xp[c + v / 2], zt[t >> 1]);
+                    else pk_fma_tap_lo(A[c], xp[c + v / 2], zt[t >> 1]);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    if (t & 1) pk_fma_tap_hi(B[c], xp[c + (v - 1) / 2], zt[t >> 1]);
+                    else pk_fma_tap_lo(B[c], xp[c + (v - 1) / 2], zt[t >> 1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        r[2 * c] = A[c].x + B[c].y;
+        r[2 * c + 1] = A[c].y + B[c + 1].x;
+    }
+}
+
+constexpr int ROW_NV = 3;        // 16-byte vectors per thread and branch that hold a plane in flight (<= 768 quads)
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global access of
+// the wave: here that would be the next plane's loads and this plane's stores, i.e. it would drain the memory pipeline
+// twice per plane.  The kernel's global reads and writes never alias, so only the LDS image needs the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int NB, int PITCH>
+__global__ __launch_bounds__(256, 4) void groupdw_row_kernel(Branch b0, Branch b1, Branch b2, const float* __restrict__ weight,
+                                                             float* __restrict__ out, int Ho, int Wo, int planes) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const Branch br[3] = {b0, b1, b2};
+    int offs[3];
+    {
+        int off = 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            offs[i] = off;
+            off += br[i].hx * PITCH;
+        }
+    }
+    float sw[3] = {1.f, 0.f, 0.f};
+    if (NB == 3) {
+        const float w0 = weight[0], w1 = weight[1], w2 = weight[2];
+        const float m = fmaxf(w0, fmaxf(w1, w2));
+        const float e0 = expf(w0 - m), e1 = expf(w1 - m), e2 = expf(w2 - m);
+        const float s = e0 + e1 + e2;
+        sw[0] = e0 / s; sw[1] = e1 / s; sw[2] = e2 / s;
+    }
+    // Staging map.  A thread owns quad column q = t % Q of rows r0 + k RPT (k = 0 .. passes-1), with Q = ceil(wx / 4)
+    // quads per row, RPT = 256 / Q rows per pass and r0 = t / Q; threads past RPT * Q repeat the last one's work and
+    // the last pass holds its row inside the plane (same data to the same LDS slot), so nothing branches per lane.
+    // Only the first and the last pass's offsets live in registers: the passes between differ by workgroup-uniform steps.
+    int passes[NB], gstep[NB], lstep[NB];
+    unsigned g_first[NB], g_last[NB];
+    int l_first[NB], l_last[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int Q = (br[i].wx + 3) >> 2, RPT = 256 / Q;
+        passes[i] = (br[i].hx + RPT - 1) / RPT;
+        const int t = min(tid, RPT * Q - 1), r0 = t / Q, q = t - r0 * Q;
+        const int rl = min(r0 + (passes[i] - 1) * RPT, br[i].hx - 1);
+        g_first[i] = (unsigned)(r0 * br[i].wx + 4 * q) * 4u;
+        g_last[i] = (unsigned)(rl * br[i].wx + 4 * q) * 4u;
+        l_first[i] = offs[i] + r0 * PITCH + 4 * q;
+        l_last[i] = offs[i] + rl * PITCH + 4 * q;
+        gstep[i] = RPT * br[i].wx * 4;
+        lstep[i] = RPT * PITCH;
+    }
+    f4v regs[NB][ROW_NV];
+    // plane p's quads into registers, by buffer loads: they take any 4-byte alignment, and the last quad of the last
+    // plane's last row, which ends up to 3 floats past the tensor, reads zeros there (the descriptor bounds the range).
+    __amdgpu_buffer_rsrc_t rx[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        rx[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(br[i].x), 0, planes * br[i].hx * br[i].wx * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, planes * Ho * Wo * 4, 0x00020000);
+    auto fetch = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int plane_bytes = p * (br[i].hx * br[i].wx * 4);
+#pragma unroll
+            for (int k = 0; k < ROW_NV; ++k) {
+                if (k >= passes[i]) continue;
+                const bool last = k == passes[i] - 1;
+                regs[i][k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(
+                    rx[i], (int)(last ? g_last[i] : g_first[i]), plane_bytes + (last ? 0 : k * gstep[i]), 0));
+            }
+        }
+    };
+    int p = blockIdx.x;
+    if (p < planes) fetch(p);
+    const int nstrip = (Wo + 7) >> 3;
+    for (; p < planes; p += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int k = 0; k < ROW_NV; ++k) {
+                if (k >= passes[i]) continue;
+                const bool last = k == passes[i] - 1;
+                *reinterpret_cast<f4v*>(smem + (last ? l_last[i] : l_first[i] + k * lstep[i])) = regs[i][k];
+            }
+        lds_barrier();
+        const int pn = p + gridDim.x;
+        if (pn < planes) fetch(pn);
+        // Items in chunks of 256 (one chunk for the 41x41 and 25x25 maps).  The taps are workgroup-uniform and come
+        // through the scalar unit; each branch's are loaded right before its pass, in uniform control flow, so that
+        // only one branch's taps occupy scalar registers at a time.
+        const int nitems = nstrip * Ho;
+        for (int base = 0; base < nitems; base += 256) {
+            const int item = base + tid;
+            const bool active = item < nitems;
+            const int strip = item / Ho, row = item - strip * Ho, j0 = strip * 8;      // rows fastest: conflict-free LDS reads
+            float acc[8], r[8];
+            {
+                f2v zt[13];
+                load_taps<25>(br[0].z + (size_t)p * 25, zt);
+                if (active) {
+                    row_strip<5, 5, PITCH>(smem + offs[0], zt, row, j0, r);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] = NB == 1 ? r[k] : sw[0] * r[k];
+                }
+            }
+            if (NB == 3) {
+                f2v zt[8];
+                load_taps<15>(br[1].z + (size_t)p * 15, zt);
+                if (active) {
+                    row_strip<3, 5, PITCH>(smem + offs[1], zt, row, j0, r);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] = acc[k] + sw[1] * r[k];
+                }
+                load_taps<15>(br[2].z + (size_t)p * 15, zt);
+                if (active) {
+                    row_strip<5, 3, PITCH>(smem + offs[2], zt, row, j0, r);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] = acc[k] + sw[2] * r[k];
+                }
+            }
+            if (active) {
+                const int obytes = (row * Wo + j0) * 4;
+                if (j0 + 8 <= Wo) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, f4v{acc[0], acc[1], acc[2], acc[3]}), ro,
+                                                           obytes, p * (Ho * Wo * 4), 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, f4v{acc[4], acc[5], acc[6], acc[7]}), ro,
+                                                           obytes + 16, p * (Ho * Wo * 4), 0);
+                } else {
+                    float* orow = out + (size_t)p * Ho * Wo + row * Wo + j0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (j0 + k < Wo) orow[k] = acc[k];
+                }
+            }
+        }
+        lds_barrier();         // everyone is done with this plane's LDS image before the next commit
+    }
+}
+
+// Shapes the row-strip kernel takes: 5x5 base template; the widest row (+ the 12-float segment of the last strip) fits the
+// pitch; a plane's quads fit ROW_NV vectors per thread.  Returns false when the shape is left to the kernels above.
+template <int NB>
+bool launch_row(const Branch* b, const float* weight, float* out, int planes, hipStream_t stream) {
+    const int Ho = b[0].hx - b[0].hz + 1, Wo = b[0].wx - b[0].wz + 1;
+    if (b[0].hz != 5 || b[0].wz != 5) return false;
+    int pitch = 0, rows = 0;
+    for (int i = 0; i < NB; ++i) {
+        const int need = ((Wo + 7) / 8 - 1) * 8 + 12;                  // last strip's segment end
+        const int wpad = ((b[i].wx + 3) / 4) * 4;
+        const int w = need > wpad ? need : wpad;
+        pitch = w > pitch ? w : pitch;
+        rows += b[i].hx;
+        const int Q = (b[i].wx + 3) / 4;
+        if (Q > 256 || (b[i].hx + 256 / Q - 1) / (256 / Q) > ROW_NV) return false;
+    }
+    const int P = pitch <= 36 ? 36 : (pitch <= 52 ? 52 : 0);           // 4 * odd: rows 0..15 fall on distinct bank quads
+    if (P == 0) return false;
+    for (int i = 0; i < NB; ++i)                                        // 32-bit byte offsets inside each tensor
+        if ((long)planes * b[i].hx * b[i].wx * 4 >= (1L << 31)) return false;
+    const size_t lds = (size_t)rows * P * sizeof(float);
+    if (lds > 40 * 1024) return false;
+    const int lds_cap = (int)((160 * 1024) / lds);
+    const int per_cu = lds_cap < 4 ? (lds_cap < 1 ? 1 : lds_cap) : 4;
+    const int grid = planes < 256 * per_cu ? planes : 256 * per_cu;
+    if (P == 36) groupdw_row_kernel<NB, 36><<<grid, 256, lds, stream>>>(b[0], b[1], b[2], weight, out, Ho, Wo, planes);
+    else groupdw_row_kernel<NB, 52><<<grid, 256, lds, stream>>>(b[0], b[1], b[2], weight, out, Ho, Wo, planes);
+    return true;
+}
+
 size_t lds_bytes(const Branch* b, int nb) {
     size_t f = 0;
     for (int i = 0; i < nb; ++i) f += plane_floats(b[i].hx, b[i].wx, b[i].hz);
@@ -452,7 +705,8 @@ extern "C" int spot_xcorr_depthwise_f32(const float* x, const float* kernel, flo
     const size_t lds = lds_bytes(b, 1);
     SPOT_CHECK_ARG(lds <= 64 * 1024, "xcorr_depthwise: search plane %dx%d does not fit the 64 KB LDS stage", hx, wx);
     SPOT_CHECK_ARG(((uintptr_t)x & 15) == 0, "xcorr_depthwise: x must be 16-byte aligned");
-    if (!(hz == 5 && wz == 5 && launch_tile<1>(b, nullptr, out, planes, stream))) launch_fwd<1, 0>(b, nullptr, out, planes, lds, stream);
+    if (!launch_row<1>(b, nullptr, out, planes, stream) && !(hz == 5 && wz == 5 && launch_tile<1>(b, nullptr, out, planes, stream)))
+        launch_fwd<1, 0>(b, nullptr, out, planes, lds, stream);
     SPOT_CHECK_LAUNCH("xcorr_depthwise");
     return SPOT_OK;
 }
@@ -471,7 +725,8 @@ extern "C" int spot_groupdw_f32(const float* x11, const float* x12, const float*
     SPOT_CHECK_ARG((((uintptr_t)x11 | (uintptr_t)x12 | (uintptr_t)x21) & 15) == 0, "groupdw: search planes must be 16-byte aligned");
     // (the register-tile kernel is not used for the triple: three input patches plus the weighted sum do not fit
     //  128 registers without spilling, and at 168 registers it loses to the column walk)
-    if (hz == 5 && wz == 5) launch_fwd<3, 5>(b, weight3, out, planes, lds, stream);
+    if (launch_row<3>(b, weight3, out, planes, stream)) {
+    } else if (hz == 5 && wz == 5) launch_fwd<3, 5>(b, weight3, out, planes, lds, stream);
     else launch_fwd<3, 0>(b, weight3, out, planes, lds, stream);
     SPOT_CHECK_LAUNCH("groupdw");
     return SPOT_OK;
