@@ -467,6 +467,14 @@ __device__ __forceinline__ void pk_fma_tap_hi(f2v& acc, f2v x, f2v taps) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(x), "s"(taps));
 }
 
+// acc += (one half of a vector register pair, broadcast) * x
+__device__ __forceinline__ void pk_fma_g_lo(f2v& acc, f2v gpair, f2v x) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(gpair), "v"(x));
+}
+__device__ __forceinline__ void pk_fma_g_hi(f2v& acc, f2v gpair, f2v x) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(gpair), "v"(x));
+}
+
 // the NT taps of one plane and branch as pairs (workgroup-uniform: scalar loads)
 template <int NT>
 __device__ __forceinline__ void load_taps(const float* __restrict__ z, f2v (&zt)[(NT + 1) / 2]) {
@@ -475,8 +483,12 @@ __device__ __forceinline__ void load_taps(const float* __restrict__ z, f2v (&zt)
     if (NT & 1) zt[NT / 2] = f2v{z[NT - 1], 0.f};
 }
 
-// r[0..8) = the 8 outputs at (row, j0 .. j0+7) of the correlation of the pitched LDS plane xs with the HZ x WZ taps
-template <int HZ, int WZ, int PITCH>
+// r[0..8) = the 8 outputs at (row, j0 .. j0+7) of the correlation of the pitched LDS plane xs with the HZ x WZ taps:
+//   r[k] = sum_{u,v} xs[row + u][j0 + k + V0 + v] * tap(u, v),   tap(u, v) = taps[u WZ + v], or taps[HZ WZ - 1 - (u WZ + v)] with REV
+// (V0 > 0 and REV serve the input gradient: a correlation of the zero-padded output gradient with the flipped taps, whose
+// window starts V0 columns into the 16-byte aligned segment).  V0 + WZ <= 5.
+// VT: the tap pairs sit in vector registers (every lane holds the same values) instead of scalar ones.
+template <int HZ, int WZ, int PITCH, int V0 = 0, bool REV = false, bool VT = false>
 __device__ __forceinline__ void row_strip(const float* xs, const f2v (&zt)[(HZ * WZ + 1) / 2], int row, int j0, float (&r)[8]) {
     f2v A[4], B[5];
 #pragma unroll
@@ -492,18 +504,29 @@ __device__ __forceinline__ void row_strip(const float* xs, const f2v (&zt)[(HZ *
         const f2v xp[6] = {x[0].xy, x[0].zw, x[1].xy, x[1].zw, x[2].xy, x[2].zw};
 #pragma unroll
         for (int v = 0; v < WZ; ++v) {
-            const int t = u * WZ + v;
-            if ((v & 1) == 0) {
+            const int t = REV ? HZ * WZ - 1 - (u * WZ + v) : u * WZ + v;
+            const int vv = v + V0;
+            if ((vv & 1) == 0) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (t & 1) pk_fma_tap_hi(A[c], xp[c + v / 2], zt[t >> 1]);
-                    else pk_fma_tap_lo(A[c], xp[c + v / 2], zt[t >> 1]);
+                    if (VT) {
+                        if (t & 1) pk_fma_g_hi(A[c], zt[t >> 1], xp[c + vv / 2]);
+                        else pk_fma_g_lo(A[c], zt[t >> 1], xp[c + vv / 2]);
+                    } else {
+                        if (t & 1) pk_fma_tap_hi(A[c], xp[c + vv / 2], zt[t >> 1]);
+                        else pk_fma_tap_lo(A[c], xp[c + vv / 2], zt[t >> 1]);
+                    }
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 5; ++c) {
-                    if (t & 1) pk_fma_tap_hi(B[c], xp[c + (v - 1) / 2], zt[t >> 1]);
-                    else pk_fma_tap_lo(B[c], xp[c + (v - 1) / 2], zt[t >> 1]);
+                    if (VT) {
+                        if (t & 1) pk_fma_g_hi(B[c], zt[t >> 1], xp[c + (vv - 1) / 2]);
+                        else pk_fma_g_lo(B[c], zt[t >> 1], xp[c + (vv - 1) / 2]);
+                    } else {
+                        if (t & 1) pk_fma_tap_hi(B[c], xp[c + (vv - 1) / 2], zt[t >> 1]);
+                        else pk_fma_tap_lo(B[c], xp[c + (vv - 1) / 2], zt[t >> 1]);
+                    }
                 }
             }
         }
@@ -532,7 +555,7 @@ __global__ __launch_bounds__(256, 4) void groupdw_row_kernel(Branch b0, Branch b
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const Branch br[3] = {b0, b1, b2};
-    int offs[3];
+    int offs[3], ostage;
     {
         int off = 0;
 #pragma unroll
@@ -540,7 +563,9 @@ __global__ __launch_bounds__(256, 4) void groupdw_row_kernel(Branch b0, Branch b
             offs[i] = off;
             off += br[i].hx * PITCH;
         }
+        ostage = off;                  // the finished map, rows at pitch OP, until the next iteration stores it
     }
+    const int OP = ((Wo + 7) >> 3) << 3;
     float sw[3] = {1.f, 0.f, 0.f};
     if (NB == 3) {
         const float w0 = weight[0], w1 = weight[1], w2 = weight[2];
@@ -590,9 +615,31 @@ __global__ __launch_bounds__(256, 4) void groupdw_row_kernel(Branch b0, Branch b
             }
         }
     };
+    // The finished map of plane q leaves through LDS so that a wave's lanes run along output rows: a row's Wo floats
+    // go out as contiguous 16-byte pieces (a few whole-line write requests per row) instead of each work item's two
+    // pieces 4 Wo bytes apart from its neighbours' (one partial-line request per lane).  It is stored one iteration
+    // late, between the barriers that fence the staging image anyway.
+    const int OQ = (Wo + 3) >> 2;                              // pieces per row; the last one may be partial
+    auto store_out = [&](int q) {
+        const int plane_bytes = q * (Ho * Wo * 4);
+        for (int idx = tid; idx < Ho * OQ; idx += 256) {
+            const int row = idx / OQ, c4 = (idx - row * OQ) * 4;
+            const f4v v = *reinterpret_cast<const f4v*>(smem + ostage + row * OP + c4);
+            const int obytes = (row * Wo + c4) * 4;
+            if (c4 + 4 <= Wo) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, v), ro, obytes, plane_bytes, 0);
+            } else {
+                float* orow = out + (size_t)q * Ho * Wo + row * Wo + c4;
+                orow[0] = v.x;
+                if (c4 + 1 < Wo) orow[1] = v.y;
+                if (c4 + 2 < Wo) orow[2] = v.z;
+            }
+        }
+    };
     int p = blockIdx.x;
     if (p < planes) fetch(p);
     const int nstrip = (Wo + 7) >> 3;
+    int prev = -1;
     for (; p < planes; p += gridDim.x) {
 #pragma unroll
         for (int i = 0; i < NB; ++i)
@@ -602,6 +649,8 @@ __global__ __launch_bounds__(256, 4) void groupdw_row_kernel(Branch b0, Branch b
                 const bool last = k == passes[i] - 1;
                 *reinterpret_cast<f4v*>(smem + (last ? l_last[i] : l_first[i] + k * lstep[i])) = regs[i][k];
             }
+        if (prev >= 0) store_out(prev);
+        prev = p;
         lds_barrier();
         const int pn = p + gridDim.x;
         if (pn < planes) fetch(pn);
@@ -639,22 +688,14 @@ __global__ __launch_bounds__(256, 4) void groupdw_row_kernel(Branch b0, Branch b
                 }
             }
             if (active) {
-                const int obytes = (row * Wo + j0) * 4;
-                if (j0 + 8 <= Wo) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, f4v{acc[0], acc[1], acc[2], acc[3]}), ro,
-                                                           obytes, p * (Ho * Wo * 4), 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, f4v{acc[4], acc[5], acc[6], acc[7]}), ro,
-                                                           obytes + 16, p * (Ho * Wo * 4), 0);
-                } else {
-                    float* orow = out + (size_t)p * Ho * Wo + row * Wo + j0;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if (j0 + k < Wo) orow[k] = acc[k];
-                }
+                float* st = smem + ostage + row * OP + j0;
+                *reinterpret_cast<f4v*>(st) = f4v{acc[0], acc[1], acc[2], acc[3]};
+                *reinterpret_cast<f4v*>(st + 4) = f4v{acc[4], acc[5], acc[6], acc[7]};
             }
         }
         lds_barrier();         // everyone is done with this plane's LDS image before the next commit
     }
+    if (prev >= 0) store_out(prev);
 }
 
 // Shapes the row-strip kernel takes: 5x5 base template; the widest row (+ the 12-float segment of the last strip) fits the
@@ -677,10 +718,11 @@ bool launch_row(const Branch* b, const float* weight, float* out, int planes, hi
     if (P == 0) return false;
     for (int i = 0; i < NB; ++i)                                        // 32-bit byte offsets inside each tensor
         if ((long)planes * b[i].hx * b[i].wx * 4 >= (1L << 31)) return false;
-    const size_t lds = (size_t)rows * P * sizeof(float);
+    const size_t lds = ((size_t)rows * P + (size_t)Ho * (((Wo + 7) / 8) * 8)) * sizeof(float);
     if (lds > 40 * 1024) return false;
     const int lds_cap = (int)((160 * 1024) / lds);
-    const int per_cu = lds_cap < 4 ? (lds_cap < 1 ? 1 : lds_cap) : 4;
+    const int reg_cap = NB == 1 ? 8 : 4;                               // 64 / 121 registers per lane
+    const int per_cu = lds_cap < reg_cap ? (lds_cap < 1 ? 1 : lds_cap) : reg_cap;
     const int grid = planes < 256 * per_cu ? planes : 256 * per_cu;
     if (P == 36) groupdw_row_kernel<NB, 36><<<grid, 256, lds, stream>>>(b[0], b[1], b[2], weight, out, Ho, Wo, planes);
     else groupdw_row_kernel<NB, 52><<<grid, 256, lds, stream>>>(b[0], b[1], b[2], weight, out, Ho, Wo, planes);
@@ -1003,6 +1045,327 @@ __global__ __launch_bounds__(256, 4) void groupdw_bwd5_kernel(Branch b0, Branch 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Row-strip backward for the (5x5, 3x5, 5x3) triple (NB = 3) or a single 5x5 template (NB = 1): the forward row
+// kernel's machinery (re-pitched LDS images filled by buffer loads, 16-byte conflict-free LDS reads, packed
+// multiply-adds on register pairs as loaded, LDS-only barriers, persistent workgroups with the next plane in flight
+// in registers, maps leaving through an LDS stage so that lanes run along rows) applied to both gradients.
+//   dz_i[u][v] = s_i sum_{i,j} g[i][j] x_i[i+u][j+v]: a work item is 8 consecutive positions of one row of g.  For
+//     tap row u it holds the 12-float segment of x row i+u and adds g[k] * (x[k+v], x[k+v+1]) into pairs of taps:
+//     even k feed the pairs (dz0,dz1)(dz2,dz3)(dz4,-), odd k the pairs (-,dz0)(dz1,dz2)(dz3,dz4): again only aligned
+//     register pairs, g[k] picked from its pair by the instruction's half selectors.  120 packed instead of 200
+//     scalar multiply-adds for 5x5.  The per-thread tap sums are reduced by the slot butterfly below.
+//   dx_i = s_i * correlation of the zero-padded g with the flipped taps: the forward's row_strip on the padded image.
+// The x images are dead after the dz pass and serve as the stages of the dx maps.
+// ---------------------------------------------------------------------------
+
+// dzr[u WZ + v] += sum_{k<8} g[row][j0+k] * xs[row+u][j0+k+v]; grow points at g[row][j0] in the padded image
+template <int HZ, int WZ, int PITCH>
+__device__ __forceinline__ void dz_item(const float* xs, const float* grow, int row, int j0, float (&dzr)[TAPS]) {
+    constexpr int NE = (WZ + 1) / 2, NO = WZ / 2 + 1;
+    const f4v g0 = *reinterpret_cast<const f4v*>(grow), g1 = *reinterpret_cast<const f4v*>(grow + 4);
+    const f2v gp[4] = {g0.xy, g0.zw, g1.xy, g1.zw};
+    const float* base = xs + row * PITCH + j0;
+#pragma unroll
+    for (int u = 0; u < HZ; ++u) {
+        f4v x[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) x[q] = *reinterpret_cast<const f4v*>(base + u * PITCH + 4 * q);
+        const f2v xp[6] = {x[0].xy, x[0].zw, x[1].xy, x[1].zw, x[2].xy, x[2].zw};
+        f2v E[NE], O[NO];          // E[m] = (dz[2m], dz[2m+1]); O[m] = (dz[2m-1], dz[2m])
+#pragma unroll
+        for (int m = 0; m < NE; ++m) E[m] = f2v{0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NO; ++m) O[m] = f2v{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if ((k & 1) == 0) {
+#pragma unroll
+                for (int m = 0; m < NE; ++m) pk_fma_g_lo(E[m], gp[k >> 1], xp[k / 2 + m]);
+            } else {
+#pragma unroll
+                for (int m = 0; m < NO; ++m) pk_fma_g_hi(O[m], gp[k >> 1], xp[(k - 1) / 2 + m]);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < WZ; ++v)
+            dzr[u * WZ + v] += (v & 1) ? E[v / 2].y + O[v / 2 + 1].x : E[v / 2].x + O[v / 2].y;
+    }
+}
+
+// Shapes are compile-time (square base plane of side HX, 5x5 base template: branch planes HX x HX, (HX-2) x HX,
+// HX x (HX-2)); with run-time shapes the three unrolled branch bodies keep more derived scalars alive than there
+// are scalar registers.
+struct BranchC {
+    int hx, wx, hz, wz;
+};
+__host__ __device__ constexpr BranchC branch_shape(int HX, int i) {
+    return i == 0 ? BranchC{HX, HX, 5, 5} : (i == 1 ? BranchC{HX - 2, HX, 3, 5} : BranchC{HX, HX - 2, 5, 3});
+}
+// pitch of the LDS images: covers the widest row, the last strip's 12-float segment and the padded g; 4 * odd
+__host__ __device__ constexpr int row_pitch(int HX) {
+    const int Wo = HX - 4;
+    int need = ((HX + 7) / 8 - 1) * 8 + 12;
+    const int a = ((Wo + 7) / 8 - 1) * 8 + 12, c = Wo + 8, d = ((HX + 3) / 4) * 4;
+    need = a > need ? a : need;
+    need = c > need ? c : need;
+    need = d > need ? d : need;
+    int p = (need + 3) / 4;
+    if (p % 2 == 0) ++p;
+    return 4 * p;
+}
+__host__ __device__ constexpr int bwd_row_lds_floats(int NB, int HX) {
+    int rows = HX - 4 + 8;
+    for (int i = 0; i < NB; ++i) rows += branch_shape(HX, i).hx;
+    return rows * row_pitch(HX);
+}
+
+template <int NB, int HX>
+__global__ __launch_bounds__(256, 3) void groupdw_bwd_row_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                                 const float* __restrict__ x2, const float* __restrict__ z0,
+                                                                 const float* __restrict__ z1, const float* __restrict__ z2,
+                                                                 const float* __restrict__ weight, const float* __restrict__ g,
+                                                                 float* __restrict__ dx0, float* __restrict__ dx1,
+                                                                 float* __restrict__ dx2, float* __restrict__ dz0,
+                                                                 float* __restrict__ dz1, float* __restrict__ dz2,
+                                                                 float* __restrict__ dsw_partial, int planes) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red[4][TAPS];
+    __shared__ __attribute__((aligned(16))) float zl[3][TAPS];          // this plane's taps (staged with the planes)
+    constexpr int PAD = 4, PITCH = row_pitch(HX), Ho = HX - 4, Wo = HX - 4, lds_floats = bwd_row_lds_floats(NB, HX);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr BranchC bc[3] = {branch_shape(HX, 0), branch_shape(HX, 1), branch_shape(HX, 2)};
+    struct BranchP {
+        const float* x;
+        const float* z;
+        int hx, wx, hz, wz;
+    };
+    const BranchP br[3] = {{x0, z0, bc[0].hx, bc[0].wx, 5, 5}, {x1, z1, bc[1].hx, bc[1].wx, 3, 5}, {x2, z2, bc[2].hx, bc[2].wx, 5, 3}};
+    float* dxs[3] = {dx0, dx1, dx2};
+    float* dzs[3] = {dz0, dz1, dz2};
+    int offs[3], goffs;
+    {
+        int off = 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            offs[i] = off;
+            off += br[i].hx * PITCH;
+        }
+        goffs = off;                   // zero-padded g: (Ho + 2 PAD) rows, g[r][c] at row r + PAD, column c + PAD
+    }
+    float sw[3] = {1.f, 0.f, 0.f};
+    if (NB == 3) {
+        const float w0 = weight[0], w1 = weight[1], w2 = weight[2];
+        const float m = fmaxf(w0, fmaxf(w1, w2));
+        const float e0 = expf(w0 - m), e1 = expf(w1 - m), e2 = expf(w2 - m);
+        const float s = e0 + e1 + e2;
+        sw[0] = e0 / s; sw[1] = e1 / s; sw[2] = e2 / s;
+    }
+    // everything that is read but never staged (the padding of g, the pitch columns of the x images) starts at zero
+    for (int i = tid; i < lds_floats; i += 256) smem[i] = 0.f;
+    // staging maps of the x planes (as in the forward kernel) and of g
+    int passes[NB], gstep[NB], lstep[NB];
+    unsigned g_first[NB], g_last[NB];
+    int l_first[NB], l_last[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int Q = (br[i].wx + 3) >> 2, RPT = 256 / Q;
+        passes[i] = (br[i].hx + RPT - 1) / RPT;
+        const int t = min(tid, RPT * Q - 1), r0 = t / Q, q = t - r0 * Q;
+        const int rl = min(r0 + (passes[i] - 1) * RPT, br[i].hx - 1);
+        g_first[i] = (unsigned)(r0 * br[i].wx + 4 * q) * 4u;
+        g_last[i] = (unsigned)(rl * br[i].wx + 4 * q) * 4u;
+        l_first[i] = offs[i] + r0 * PITCH + 4 * q;
+        l_last[i] = offs[i] + rl * PITCH + 4 * q;
+        gstep[i] = RPT * br[i].wx * 4;
+        lstep[i] = RPT * PITCH;
+    }
+    const int GQ = (Wo + 3) >> 2, GRPT = 256 / GQ, gpasses = (Ho + GRPT - 1) / GRPT;     // gpasses <= 2 (host)
+    unsigned gg[2];
+    int gl[2], gvalid;                 // floats of this thread's quad that lie inside a row of g (the rest must stay 0)
+    {
+        const int t = min(tid, GRPT * GQ - 1), r0 = t / GQ, q = t - r0 * GQ;
+        const int r1 = min(r0 + GRPT, Ho - 1);
+        gg[0] = (unsigned)(r0 * Wo + 4 * q) * 4u;
+        gg[1] = (unsigned)(r1 * Wo + 4 * q) * 4u;
+        gl[0] = goffs + (r0 + PAD) * PITCH + PAD + 4 * q;
+        gl[1] = goffs + (r1 + PAD) * PITCH + PAD + 4 * q;
+        gvalid = min(4, Wo - 4 * q);
+    }
+    // Buffer descriptors are made per plane (base = the plane, range = its bytes: the 3 floats a row's last quad runs
+    // past the plane read as zeros) right where they are used: kept for the whole launch they would crowd the
+    // scalar registers.
+    f4v regs[NB][ROW_NV], gregs[2];
+    float zreg[NB];
+    auto fetch = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int n = br[i].hx * br[i].wx;
+            __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(br[i].x) + (size_t)p * n, 0, n * 4, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < ROW_NV; ++k) {
+                if (k >= passes[i]) continue;
+                const bool last = k == passes[i] - 1;
+                regs[i][k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(
+                    rx, (int)(last ? g_last[i] : g_first[i]), last ? 0 : k * gstep[i], 0));
+            }
+            const int nt = br[i].hz * br[i].wz;
+            zreg[i] = br[i].z[(size_t)p * nt + min(tid, nt - 1)];
+        }
+        __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g) + (size_t)p * Ho * Wo, 0, Ho * Wo * 4, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (k < gpasses) gregs[k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)gg[k], 0, 0));
+    };
+    // rows of dx_i out of its stage (rows at pitch SP in x image region `reg`), lanes along rows
+    auto store_dx = [&](int i, int reg, int q) {
+        if (!dxs[i]) return;
+        const int hx = br[i].hx, wx = br[i].wx, SP = ((wx + 7) >> 3) << 3, OQ = (wx + 3) >> 2;
+        __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(dxs[i] + (size_t)q * hx * wx, 0, hx * wx * 4, 0x00020000);
+        for (int idx = tid; idx < hx * OQ; idx += 256) {
+            const int row = idx / OQ, c4 = (idx - row * OQ) * 4;
+            const f4v v = *reinterpret_cast<const f4v*>(smem + offs[reg] + row * SP + c4);
+            if (c4 + 4 <= wx) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, v), rdx, (row * wx + c4) * 4, 0, 0);
+            } else {
+                float* orow = dxs[i] + (size_t)q * hx * wx + row * wx + c4;
+                orow[0] = v.x;
+                if (c4 + 1 < wx) orow[1] = v.y;
+                if (c4 + 2 < wx) orow[2] = v.z;
+            }
+        }
+    };
+    int p = blockIdx.x;
+    if (p < planes) fetch(p);
+    lds_barrier();                     // the zero fill is done before the first commit
+    for (; p < planes; p += gridDim.x) {
+        // ---- commit the staged planes
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int k = 0; k < ROW_NV; ++k) {
+                if (k >= passes[i]) continue;
+                const bool last = k == passes[i] - 1;
+                *reinterpret_cast<f4v*>(smem + (last ? l_last[i] : l_first[i] + k * lstep[i])) = regs[i][k];
+            }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (k < gpasses) {
+                f4v v = gregs[k];
+                if (gvalid < 2) v.y = 0.f;
+                if (gvalid < 3) v.z = 0.f;
+                if (gvalid < 4) v.w = 0.f;
+                *reinterpret_cast<f4v*>(smem + gl[k]) = v;
+            }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (tid < TAPS) zl[i][tid] = tid < br[i].hz * br[i].wz ? zreg[i] : 0.f;
+        lds_barrier();
+        const int pn = p + gridDim.x;
+        if (pn < planes) fetch(pn);
+        // ---- dz_i and ds_i
+        const int nstrip_g = (Wo + 7) >> 3, nitems_g = nstrip_g * Ho;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            float acc[TAPS];
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) acc[k] = 0.f;
+            for (int base = 0; base < nitems_g; base += 256) {
+                const int item = base + tid;
+                if (item < nitems_g) {
+                    const int strip = item / Ho, row = item - strip * Ho, j0 = strip * 8;
+                    const float* grow = smem + goffs + (row + PAD) * PITCH + PAD + j0;
+                    if (i == 0) dz_item<5, 5, PITCH>(smem + offs[0], grow, row, j0, acc);
+                    if (i == 1) dz_item<3, 5, PITCH>(smem + offs[1], grow, row, j0, acc);
+                    if (i == 2) dz_item<5, 3, PITCH>(smem + offs[2], grow, row, j0, acc);
+                }
+            }
+            const float tot = reduce_slots(acc, lane);
+            if (lane < 32) red[wave][slot_of_lane(lane)] = tot;
+            lds_barrier();
+            if (tid < 64) {
+                const int nt = br[i].hz * br[i].wz;
+                float zs = 0.f;
+                if (tid < nt) {
+                    const float t = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+                    if (dzs[i]) dzs[i][(size_t)p * nt + tid] = sw[i] * t;
+                    zs = zl[i][tid] * t;
+                }
+                zs = wave_sum(zs);
+                if (NB == 3 && dsw_partial && tid == 0) dsw_partial[(size_t)p * 3 + i] = zs;
+            }
+            lds_barrier();             // red is free again; after the last branch: nobody reads the x images any more
+        }
+        // ---- dx_i = s_i * corr(padded g, flipped taps), staged in the x image regions 0, 1, 0
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (!dxs[i]) continue;
+            const int hx = br[i].hx, wx = br[i].wx, SP = ((wx + 7) >> 3) << 3, reg = i & 1;
+            const int nitems = ((wx + 7) >> 3) * hx;
+            // window origin of this branch inside the padding: rows PAD - (hz - 1), columns PAD - (wz - 1)
+            const float* origin = smem + goffs + (PAD - (br[i].hz - 1)) * PITCH;
+            for (int base = 0; base < nitems; base += 256) {
+                const int item = base + tid;
+                const bool active = item < nitems;
+                const int strip = item / hx, row = item - strip * hx, j0 = strip * 8;
+                float r[8];
+                if (active) {          // the taps: broadcast 8-byte LDS reads, every lane gets the same pairs
+                    if (i == 0) {
+                        f2v zt[13];
+#pragma unroll
+                        for (int m = 0; m < 13; ++m) zt[m] = *reinterpret_cast<const f2v*>(&zl[0][2 * m]);
+                        row_strip<5, 5, PITCH, 0, true, true>(origin, zt, row, j0, r);
+                    }
+                    if (i == 1) {
+                        f2v zt[8];
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) zt[m] = *reinterpret_cast<const f2v*>(&zl[1][2 * m]);
+                        row_strip<3, 5, PITCH, 0, true, true>(origin, zt, row, j0, r);
+                    }
+                    if (i == 2) {
+                        f2v zt[8];
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) zt[m] = *reinterpret_cast<const f2v*>(&zl[2][2 * m]);
+                        row_strip<5, 3, PITCH, 2, true, true>(origin, zt, row, j0, r);
+                    }
+                }
+                if (active) {
+                    float* st = smem + offs[reg] + row * SP + j0;
+                    *reinterpret_cast<f4v*>(st) = f4v{sw[i] * r[0], sw[i] * r[1], sw[i] * r[2], sw[i] * r[3]};
+                    *reinterpret_cast<f4v*>(st + 4) = f4v{sw[i] * r[4], sw[i] * r[5], sw[i] * r[6], sw[i] * r[7]};
+                }
+            }
+            lds_barrier();
+            store_dx(i, reg, p);
+        }
+        lds_barrier();                 // stages read out, padded g no longer needed: the next commit may overwrite
+    }
+}
+
+// Shapes the backward row kernel is built for: square base plane of side 45 (384^2 search crop) or 29 (255^2), 5x5
+// base template, tensors below 2 GiB; false leaves the call to the kernels above.
+template <int NB, int HX>
+void launch_bwd_row_hx(const Branch* b, const float* weight, const float* g, float** dx, float** dz, float* dsw, int planes,
+                       hipStream_t stream) {
+    constexpr size_t lds = (size_t)bwd_row_lds_floats(NB, HX) * sizeof(float);
+    constexpr int lds_cap = (int)((160 * 1024 - 4 * 1024) / lds);
+    constexpr int per_cu = lds_cap < 3 ? (lds_cap < 1 ? 1 : lds_cap) : 3;
+    const int grid = planes < 256 * per_cu ? planes : 256 * per_cu;
+    groupdw_bwd_row_kernel<NB, HX><<<grid, 256, lds, stream>>>(b[0].x, b[1].x, b[2].x, b[0].z, b[1].z, b[2].z, weight, g, dx[0],
+                                                               dx[1], dx[2], dz[0], dz[1], dz[2], dsw, planes);
+}
+
+template <int NB>
+bool launch_bwd_row(const Branch* b, const float* weight, const float* g, float** dx, float** dz, float* dsw, int planes,
+                    hipStream_t stream) {
+    const int HX = b[0].hx;
+    if (b[0].hz != 5 || b[0].wz != 5 || b[0].wx != HX || (HX != 45 && HX != 29)) return false;
+    if ((long)planes * HX * HX * 4 >= (1L << 31)) return false;
+    if (HX == 45) launch_bwd_row_hx<NB, 45>(b, weight, g, dx, dz, dsw, planes, stream);
+    else launch_bwd_row_hx<NB, 29>(b, weight, g, dx, dz, dsw, planes, stream);
+    return true;
+}
+
 int launch_bwd(const Branch* b, int nb, const float* weight, const float* g, float** dx, float** dz, float* dsw,
                int planes, hipStream_t stream) {
     const int Ho = b[0].hx - b[0].hz + 1, Wo = b[0].wx - b[0].wz + 1;
@@ -1012,6 +1375,11 @@ int launch_bwd(const Branch* b, int nb, const float* weight, const float* g, flo
         pad = b[i].wz - 1 > pad ? b[i].wz - 1 : pad;
     }
     SPOT_CHECK_ARG(pad <= GPAD_MAX, "xcorr backward: template extent %d exceeds %d", pad + 1, GPAD_MAX + 1);
+    if (nb == 3 ? launch_bwd_row<3>(b, weight, g, dx, dz, dsw, planes, stream)
+                : (nb == 1 && launch_bwd_row<1>(b, weight, g, dx, dz, dsw, planes, stream))) {
+        SPOT_CHECK_LAUNCH("xcorr backward");
+        return SPOT_OK;
+    }
     const bool five = b[0].hz == 5 && b[0].wz == 5 && ((Ho + R - 1) / R) * Wo <= 256;   // one dz item per thread
     if (five) {
         int rows = 0;
