@@ -475,6 +475,14 @@ __device__ __forceinline__ void pk_fma_g_hi(f2v& acc, f2v gpair, f2v x) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(gpair), "v"(x));
 }
 
+// acc = (one half of a vector register pair, broadcast) * x: the first product of a sum, which then needs no zero fill
+__device__ __forceinline__ void pk_mul_g_lo(f2v& acc, f2v gpair, f2v x) {
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc) : "v"(gpair), "v"(x));
+}
+__device__ __forceinline__ void pk_mul_g_hi(f2v& acc, f2v gpair, f2v x) {
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(acc) : "v"(gpair), "v"(x));
+}
+
 // the NT taps of one plane and branch as pairs (workgroup-uniform: scalar loads)
 template <int NT>
 __device__ __forceinline__ void load_taps(const float* __restrict__ z, f2v (&zt)[(NT + 1) / 2]) {
@@ -565,7 +573,7 @@ __global__ __launch_bounds__(256, 4) void groupdw_row_kernel(Branch b0, Branch b
         }
         ostage = off;                  // the finished map, rows at pitch OP, until the next iteration stores it
     }
-    const int OP = ((Wo + 7) >> 3) << 3;
+    constexpr int OP = PITCH;          // 4 * odd: the rows-fastest stage writes hit distinct bank quads
     float sw[3] = {1.f, 0.f, 0.f};
     if (NB == 3) {
         const float w0 = weight[0], w1 = weight[1], w2 = weight[2];
@@ -718,7 +726,7 @@ bool launch_row(const Branch* b, const float* weight, float* out, int planes, hi
     if (P == 0) return false;
     for (int i = 0; i < NB; ++i)                                        // 32-bit byte offsets inside each tensor
         if ((long)planes * b[i].hx * b[i].wx * 4 >= (1L << 31)) return false;
-    const size_t lds = ((size_t)rows * P + (size_t)Ho * (((Wo + 7) / 8) * 8)) * sizeof(float);
+    const size_t lds = ((size_t)rows * P + (size_t)Ho * P) * sizeof(float);
     if (lds > 40 * 1024) return false;
     const int lds_cap = (int)((160 * 1024) / lds);
     const int reg_cap = NB == 1 ? 8 : 4;                               // 64 / 121 registers per lane
@@ -1056,11 +1064,11 @@ __global__ __launch_bounds__(256, 4) void groupdw_bwd5_kernel(Branch b0, Branch 
 //     register pairs, g[k] picked from its pair by the instruction's half selectors.  120 packed instead of 200
 //     scalar multiply-adds for 5x5.  The per-thread tap sums are reduced by the slot butterfly below.
 //   dx_i = s_i * correlation of the zero-padded g with the flipped taps: the forward's row_strip on the padded image.
-// The x images are dead after the dz pass and serve as the stages of the dx maps.
 // ---------------------------------------------------------------------------
 
 // dzr[u WZ + v] += sum_{k<8} g[row][j0+k] * xs[row+u][j0+k+v]; grow points at g[row][j0] in the padded image
-template <int HZ, int WZ, int PITCH>
+// FIRST: the item is the thread's first of this plane and branch: its sums are stored instead of added
+template <int HZ, int WZ, int PITCH, bool FIRST>
 __device__ __forceinline__ void dz_item(const float* xs, const float* grow, int row, int j0, float (&dzr)[TAPS]) {
     constexpr int NE = (WZ + 1) / 2, NO = WZ / 2 + 1;
     const f4v g0 = *reinterpret_cast<const f4v*>(grow), g1 = *reinterpret_cast<const f4v*>(grow + 4);
@@ -1074,22 +1082,26 @@ __device__ __forceinline__ void dz_item(const float* xs, const float* grow, int 
         const f2v xp[6] = {x[0].xy, x[0].zw, x[1].xy, x[1].zw, x[2].xy, x[2].zw};
         f2v E[NE], O[NO];          // E[m] = (dz[2m], dz[2m+1]); O[m] = (dz[2m-1], dz[2m])
 #pragma unroll
-        for (int m = 0; m < NE; ++m) E[m] = f2v{0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < NO; ++m) O[m] = f2v{0.f, 0.f};
-#pragma unroll
         for (int k = 0; k < 8; ++k) {
             if ((k & 1) == 0) {
 #pragma unroll
-                for (int m = 0; m < NE; ++m) pk_fma_g_lo(E[m], gp[k >> 1], xp[k / 2 + m]);
+                for (int m = 0; m < NE; ++m) {
+                    if (k == 0) pk_mul_g_lo(E[m], gp[0], xp[m]);
+                    else pk_fma_g_lo(E[m], gp[k >> 1], xp[k / 2 + m]);
+                }
             } else {
 #pragma unroll
-                for (int m = 0; m < NO; ++m) pk_fma_g_hi(O[m], gp[k >> 1], xp[(k - 1) / 2 + m]);
+                for (int m = 0; m < NO; ++m) {
+                    if (k == 1) pk_mul_g_hi(O[m], gp[0], xp[m]);
+                    else pk_fma_g_hi(O[m], gp[k >> 1], xp[(k - 1) / 2 + m]);
+                }
             }
         }
 #pragma unroll
-        for (int v = 0; v < WZ; ++v)
-            dzr[u * WZ + v] += (v & 1) ? E[v / 2].y + O[v / 2 + 1].x : E[v / 2].x + O[v / 2].y;
+        for (int v = 0; v < WZ; ++v) {
+            const float t = (v & 1) ? E[v / 2].y + O[v / 2 + 1].x : E[v / 2].x + O[v / 2].y;
+            dzr[u * WZ + v] = FIRST ? t : dzr[u * WZ + v] + t;
+        }
     }
 }
 
@@ -1120,8 +1132,11 @@ __host__ __device__ constexpr int bwd_row_lds_floats(int NB, int HX) {
     return rows * row_pitch(HX);
 }
 
-template <int NB, int HX>
-__global__ __launch_bounds__(256, 3) void groupdw_bwd_row_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+// PART: 0 = both gradients in one launch, 1 = dz / ds only, 2 = dx only (stages g and the taps alone).  Two launches read g
+// twice, but each half needs fewer registers and less LDS than the whole: more workgroups per CU to hide the latencies of
+// the many short dependent phases of a plane.
+template <int NB, int HX, int PART>
+__global__ __launch_bounds__(256, PART == 0 ? 3 : 4) void groupdw_bwd_row_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                                  const float* __restrict__ x2, const float* __restrict__ z0,
                                                                  const float* __restrict__ z1, const float* __restrict__ z2,
                                                                  const float* __restrict__ weight, const float* __restrict__ g,
@@ -1132,7 +1147,8 @@ __global__ __launch_bounds__(256, 3) void groupdw_bwd_row_kernel(const float* __
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[4][TAPS];
     __shared__ __attribute__((aligned(16))) float zl[3][TAPS];          // this plane's taps (staged with the planes)
-    constexpr int PAD = 4, PITCH = row_pitch(HX), Ho = HX - 4, Wo = HX - 4, lds_floats = bwd_row_lds_floats(NB, HX);
+    constexpr int PAD = 4, PITCH = row_pitch(HX), Ho = HX - 4, Wo = HX - 4, lds_floats = bwd_row_lds_floats(PART == 2 ? 0 : NB, HX);
+    constexpr bool DZ = PART != 2, DX = PART != 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr BranchC bc[3] = {branch_shape(HX, 0), branch_shape(HX, 1), branch_shape(HX, 2)};
     struct BranchP {
@@ -1149,7 +1165,7 @@ __global__ __launch_bounds__(256, 3) void groupdw_bwd_row_kernel(const float* __
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             offs[i] = off;
-            off += br[i].hx * PITCH;
+            if (DZ) off += br[i].hx * PITCH;
         }
         goffs = off;                   // zero-padded g: (Ho + 2 PAD) rows, g[r][c] at row r + PAD, column c + PAD
     }
@@ -1204,7 +1220,7 @@ __global__ __launch_bounds__(256, 3) void groupdw_bwd_row_kernel(const float* __
             __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(br[i].x) + (size_t)p * n, 0, n * 4, 0x00020000);
 #pragma unroll
             for (int k = 0; k < ROW_NV; ++k) {
-                if (k >= passes[i]) continue;
+                if (!DZ || k >= passes[i]) continue;
                 const bool last = k == passes[i] - 1;
                 regs[i][k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(
                     rx, (int)(last ? g_last[i] : g_first[i]), last ? 0 : k * gstep[i], 0));
@@ -1217,24 +1233,6 @@ __global__ __launch_bounds__(256, 3) void groupdw_bwd_row_kernel(const float* __
         for (int k = 0; k < 2; ++k)
             if (k < gpasses) gregs[k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)gg[k], 0, 0));
     };
-    // rows of dx_i out of its stage (rows at pitch SP in x image region `reg`), lanes along rows
-    auto store_dx = [&](int i, int reg, int q) {
-        if (!dxs[i]) return;
-        const int hx = br[i].hx, wx = br[i].wx, SP = ((wx + 7) >> 3) << 3, OQ = (wx + 3) >> 2;
-        __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(dxs[i] + (size_t)q * hx * wx, 0, hx * wx * 4, 0x00020000);
-        for (int idx = tid; idx < hx * OQ; idx += 256) {
-            const int row = idx / OQ, c4 = (idx - row * OQ) * 4;
-            const f4v v = *reinterpret_cast<const f4v*>(smem + offs[reg] + row * SP + c4);
-            if (c4 + 4 <= wx) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, v), rdx, (row * wx + c4) * 4, 0, 0);
-            } else {
-                float* orow = dxs[i] + (size_t)q * hx * wx + row * wx + c4;
-                orow[0] = v.x;
-                if (c4 + 1 < wx) orow[1] = v.y;
-                if (c4 + 2 < wx) orow[2] = v.z;
-            }
-        }
-    };
     int p = blockIdx.x;
     if (p < planes) fetch(p);
     lds_barrier();                     // the zero fill is done before the first commit
@@ -1244,7 +1242,7 @@ __global__ __launch_bounds__(256, 3) void groupdw_bwd_row_kernel(const float* __
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int k = 0; k < ROW_NV; ++k) {
-                if (k >= passes[i]) continue;
+                if (!DZ || k >= passes[i]) continue;
                 const bool last = k == passes[i] - 1;
                 *reinterpret_cast<f4v*>(smem + (last ? l_last[i] : l_first[i] + k * lstep[i])) = regs[i][k];
             }
@@ -1266,18 +1264,25 @@ __global__ __launch_bounds__(256, 3) void groupdw_bwd_row_kernel(const float* __
         // ---- dz_i and ds_i
         const int nstrip_g = (Wo + 7) >> 3, nitems_g = nstrip_g * Ho;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
+        for (int i = 0; i < (DZ ? NB : 0); ++i) {
             float acc[TAPS];
 #pragma unroll
             for (int k = 0; k < TAPS; ++k) acc[k] = 0.f;
+#pragma unroll
             for (int base = 0; base < nitems_g; base += 256) {
                 const int item = base + tid;
                 if (item < nitems_g) {
                     const int strip = item / Ho, row = item - strip * Ho, j0 = strip * 8;
                     const float* grow = smem + goffs + (row + PAD) * PITCH + PAD + j0;
-                    if (i == 0) dz_item<5, 5, PITCH>(smem + offs[0], grow, row, j0, acc);
-                    if (i == 1) dz_item<3, 5, PITCH>(smem + offs[1], grow, row, j0, acc);
-                    if (i == 2) dz_item<5, 3, PITCH>(smem + offs[2], grow, row, j0, acc);
+                    if (base == 0) {
+                        if (i == 0) dz_item<5, 5, PITCH, true>(smem + offs[0], grow, row, j0, acc);
+                        if (i == 1) dz_item<3, 5, PITCH, true>(smem + offs[1], grow, row, j0, acc);
+                        if (i == 2) dz_item<5, 3, PITCH, true>(smem + offs[2], grow, row, j0, acc);
+                    } else {
+                        if (i == 0) dz_item<5, 5, PITCH, false>(smem + offs[0], grow, row, j0, acc);
+                        if (i == 1) dz_item<3, 5, PITCH, false>(smem + offs[1], grow, row, j0, acc);
+                        if (i == 2) dz_item<5, 3, PITCH, false>(smem + offs[2], grow, row, j0, acc);
+                    }
                 }
             }
             const float tot = reduce_slots(acc, lane);
@@ -1296,16 +1301,17 @@ __global__ __launch_bounds__(256, 3) void groupdw_bwd_row_kernel(const float* __
             }
             lds_barrier();             // red is free again; after the last branch: nobody reads the x images any more
         }
-        // ---- dx_i = s_i * corr(padded g, flipped taps), staged in the x image regions 0, 1, 0
+        // ---- dx_i = s_i * corr(padded g, flipped taps)
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
+        for (int i = 0; i < (DX ? NB : 0); ++i) {
             if (!dxs[i]) continue;
-            const int hx = br[i].hx, wx = br[i].wx, SP = ((wx + 7) >> 3) << 3, reg = i & 1;
+            const int hx = br[i].hx, wx = br[i].wx;
             const int nitems = ((wx + 7) >> 3) * hx;
             // window origin of this branch inside the padding: rows PAD - (hz - 1), columns PAD - (wz - 1)
             const float* origin = smem + goffs + (PAD - (br[i].hz - 1)) * PITCH;
             for (int base = 0; base < nitems; base += 256) {
-                const int item = base + tid;
+                // the items past the first 256 (a few rows of the last strip) go to a different wave for every branch
+                const int item = base + (base == 0 ? tid : ((tid + 192 - 64 * i) & 255));
                 const bool active = item < nitems;
                 const int strip = item / hx, row = item - strip * hx, j0 = strip * 8;
                 float r[8];
@@ -1330,29 +1336,48 @@ __global__ __launch_bounds__(256, 3) void groupdw_bwd_row_kernel(const float* __
                     }
                 }
                 if (active) {
-                    float* st = smem + offs[reg] + row * SP + j0;
-                    *reinterpret_cast<f4v*>(st) = f4v{sw[i] * r[0], sw[i] * r[1], sw[i] * r[2], sw[i] * r[3]};
-                    *reinterpret_cast<f4v*>(st + 4) = f4v{sw[i] * r[4], sw[i] * r[5], sw[i] * r[6], sw[i] * r[7]};
+                    // straight from registers: the LDS pipe is this kernel's busiest unit (a stage for coalesced rows, as
+                    // in the forward kernel, costs it more than the partial-line writes cost the L2)
+                    const f4v lo = f4v{sw[i] * r[0], sw[i] * r[1], sw[i] * r[2], sw[i] * r[3]};
+                    const f4v hi = f4v{sw[i] * r[4], sw[i] * r[5], sw[i] * r[6], sw[i] * r[7]};
+                    if (j0 + 8 <= wx) {
+                        __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(dxs[i] + (size_t)p * hx * wx, 0, hx * wx * 4, 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, lo), rdx, (row * wx + j0) * 4, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, hi), rdx, (row * wx + j0) * 4 + 16, 0, 0);
+                    } else {
+                        float* orow = dxs[i] + (size_t)p * hx * wx + row * wx + j0;
+                        const float vals[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (j0 + k < wx) orow[k] = vals[k];
+                    }
                 }
             }
-            lds_barrier();
-            store_dx(i, reg, p);
         }
-        lds_barrier();                 // stages read out, padded g no longer needed: the next commit may overwrite
+        lds_barrier();                 // the padded g is no longer needed: the next commit may overwrite it
     }
 }
 
 // Shapes the backward row kernel is built for: square base plane of side 45 (384^2 search crop) or 29 (255^2), 5x5
 // base template, tensors below 2 GiB; false leaves the call to the kernels above.
+template <int NB, int HX, int PART>
+void launch_bwd_row_part(const Branch* b, const float* weight, const float* g, float** dx, float** dz, float* dsw, int planes,
+                         hipStream_t stream) {
+    constexpr size_t lds = (size_t)bwd_row_lds_floats(PART == 2 ? 0 : NB, HX) * sizeof(float);
+    constexpr int lds_cap = (int)((160 * 1024) / (lds + 2048));         // + the static arrays and allocation granularity
+    constexpr int reg_cap = PART == 0 ? 3 : 4;
+    constexpr int per_cu = lds_cap < reg_cap ? (lds_cap < 1 ? 1 : lds_cap) : reg_cap;
+    const int grid = planes < 256 * per_cu ? planes : 256 * per_cu;
+    groupdw_bwd_row_kernel<NB, HX, PART><<<grid, 256, lds, stream>>>(b[0].x, b[1].x, b[2].x, b[0].z, b[1].z, b[2].z, weight, g,
+                                                                     dx[0], dx[1], dx[2], dz[0], dz[1], dz[2], dsw, planes);
+}
+
+// One launch for both gradients.  Measured on MI355X at 384^2 / B = 128: the whole (PART 0) 646 us; dz alone (PART 1) 345 us
+// plus dx alone (PART 2) 375 us = 715 us, because g is read twice and the dx half is bound by its write stream either way.
 template <int NB, int HX>
 void launch_bwd_row_hx(const Branch* b, const float* weight, const float* g, float** dx, float** dz, float* dsw, int planes,
                        hipStream_t stream) {
-    constexpr size_t lds = (size_t)bwd_row_lds_floats(NB, HX) * sizeof(float);
-    constexpr int lds_cap = (int)((160 * 1024 - 4 * 1024) / lds);
-    constexpr int per_cu = lds_cap < 3 ? (lds_cap < 1 ? 1 : lds_cap) : 3;
-    const int grid = planes < 256 * per_cu ? planes : 256 * per_cu;
-    groupdw_bwd_row_kernel<NB, HX><<<grid, 256, lds, stream>>>(b[0].x, b[1].x, b[2].x, b[0].z, b[1].z, b[2].z, weight, g, dx[0],
-                                                               dx[1], dx[2], dz[0], dz[1], dz[2], dsw, planes);
+    launch_bwd_row_part<NB, HX, 0>(b, weight, g, dx, dz, dsw, planes, stream);
 }
 
 template <int NB>
