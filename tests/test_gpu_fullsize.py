@@ -160,3 +160,72 @@ def test_gemm_checksums_at_ffn_size(ops):
         np.testing.assert_allclose(Cd.sum(0).cpu().numpy(), (Ad.sum(0) @ Bd.t()).cpu().numpy(), rtol=0, atol=2e-2)
         rows = torch.arange(0, M, 4099, device=DEV)
         np.testing.assert_allclose(Cd[rows].cpu().numpy(), (Ad[rows] @ Bd.t()).cpu().numpy(), rtol=0, atol=2e-5)
+
+
+def test_teacher_shard_of_128_clips_at_cfg3_size():
+    """One rank's shard of the 1024-clip pseudo-labelling configuration (128 clips, eval mode): permuting the clips
+    permutes every output bit for bit, and the shard processed as four blocks of 32 clips gives the same bits as the
+    whole shard at once (no kernel's arithmetic depends on the batch size)."""
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.dist import shard_range
+    from spot_amd.middleware import SparseMiddleware
+    from spot_amd.tensordict import TensorDict
+    from spot_amd.transt import transt_resnet50
+    S = Settings()
+    net = det_fill_(transt_resnet50(Settings(device="cpu")), 33).to(DEV).eval()
+    actor = TranstSparseActor(S, net, net, None)
+    mw = SparseMiddleware(S)
+    B = 128
+    data, mid = unsup_batch(B, 17, device=DEV)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).to(DEV)
+
+    def run(sel):
+        d = TensorDict({k: v[sel].contiguous() for k, v in data.items() if k.startswith(("key_", "unlabeled_"))})
+        m = {k: v[sel].contiguous() for k, v in mid.items()}
+        pseudo = actor(mode="inference", teacher_data=d)
+        return pseudo, mw.record_relay_results(m, pseudo)
+
+    with torch.no_grad():
+        # centre the confidences on the threshold so that both outcomes of the filter occur
+        conf = run(slice(0, B))[0]["best_conf"].clamp(1e-6, 1 - 1e-6)
+        net.iou_embed.layers[2].bias += float(np.log(0.85 / 0.15)) - torch.log(conf / (1 - conf)).median()
+        p0, r0 = run(slice(0, B))
+        p1, r1 = run(perm)
+        parts = [run(slice(*shard_range(B, r, 4))) for r in range(4)]
+    assert 0 < int(r0["aug_success"].sum()) < B
+    for k in ("best_bbox", "best_score", "best_conf"):
+        assert torch.equal(p0[k][perm], p1[k]), k
+        assert torch.equal(torch.cat([p[k] for p, _ in parts]), p0[k]), k
+    for k in ("aug_success", "aug_anno"):
+        assert torch.equal(r0[k][perm], r1[k]), k
+        assert torch.equal(torch.cat([r[k] for _, r in parts]), r0[k]), k
+
+
+def test_student_step_of_64_pairs_with_bf16_attention_at_cfg4_size():
+    """The training configuration's per-GPU batch (16 labelled + 48 pseudo-labelled pairs) with bf16 attention products
+    against the same step with exact fp32 products: loss within 1e-2 relative, gradient cosine >= 0.999, and the bf16
+    kernels really ran."""
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.criterion import transt_loss
+    from spot_amd.tensordict import TensorDict
+    from spot_amd.transt import transt_resnet50
+    from tests.test_oracle_model import student_batches
+    S = Settings(dropout=0.0)
+    sup, sp = student_batches(41, 16, 48)
+    grads, losses = [], []
+    for dtype in ("f32", "bf16"):
+        net = det_fill_(transt_resnet50(Settings(device="cpu", dropout=0.0)), 41).to(DEV).train()
+        net.featurefusion_network.set_attention_dtype(dtype)
+        actor = TranstSparseActor(S, net, net, transt_loss(S))
+        loss, _ = actor(mode="spsup", burnin_data=TensorDict({k: v.to(DEV) for k, v in sup.items()}),
+                        sp_data=TensorDict({k: v.to(DEV) for k, v in sp.items()}))
+        loss.backward()
+        losses.append(loss.item())
+        grads.append(torch.cat([p.grad.flatten() for _, p in net.named_parameters() if p.grad is not None]).double())
+        del net, actor, loss
+        torch.cuda.empty_cache()
+    assert np.isfinite(losses).all()
+    np.testing.assert_allclose(losses[1], losses[0], rtol=1e-2)
+    cos = float((grads[0] @ grads[1]) / (grads[0].norm() * grads[1].norm()))
+    assert cos >= 0.999, cos
+    assert not torch.equal(grads[0], grads[1])
