@@ -125,6 +125,26 @@ int spot_box_iou_pair_f32(const float* boxes1, const float* boxes2, int cxcywh, 
 int spot_box_giou_pair_bwd_f32(const float* boxes1_cxcywh, const float* boxes2_cxcywh, const float* d_giou,
                                const float* d_iou, float* d_boxes1, int P, hipStream_t stream);
 
+/* Set criterion of the transformer tracker, SetCriterionTransT.forward with the token sets of TrackingMatcher given as
+ * dense maps (ltr/models/tracking/transt_criterion.py:40-109,136-170; spot_match_masks writes pos / neg).
+ * logits [B,L,2], boxes [B,L,4] cxcywh, iou_pred [B,L] or NULL (no IoU head: the unsupervised branch), gt [B,4] cxcywh,
+ * pos [B,L] u8, neg [B,L] u8 multiplicities or NULL; w_obj / w_eos = the class weights (1, eos_coef).
+ * losses[5] = (loss_ce, loss_bbox, loss_giou, iou, loss_iou_pred); norms[3] = (sum of class weights, max(#pos,1),
+ * max(#neg,1)) is what the backward call divides by.  Two launches, no atomics: the same bits on every run.
+ * ws: spot_transt_loss_ws_floats() floats. */
+long spot_transt_loss_ws_floats(void);
+int spot_transt_loss_f32(const float* logits, const float* boxes, const float* iou_pred, const float* gt,
+                         const unsigned char* pos, const unsigned char* neg, float w_obj, float w_eos, int B, int L,
+                         float* losses, float* norms, float* ws, hipStream_t stream);
+/* Gradient of the four trained terms w.r.t. logits / boxes / iou_pred (any output may be NULL).  g_* point at the
+ * upstream gradient of each term on the device (NULL = 0); the IoU target of the IoU head is a constant, as in
+ * transt_criterion.py:92,103. */
+int spot_transt_loss_bwd_f32(const float* logits, const float* boxes, const float* iou_pred, const float* gt,
+                             const unsigned char* pos, const unsigned char* neg, float w_obj, float w_eos,
+                             const float* norms, const float* g_ce, const float* g_bbox, const float* g_giou,
+                             const float* g_iou_pred, int B, int L, float* d_logits, float* d_boxes, float* d_iou_pred,
+                             hipStream_t stream);
+
 /* ---- depthwise cross-correlation head ------------------------------------- */
 
 /* xcorr_depthwise, ltr/models/neck/ocean_fusion.py:238-247.  x [planes,hx,wx], kernel [planes,hz,wz]
@@ -292,6 +312,13 @@ int spot_dropout_f32(const float* x, float* out, long rows, int cols, float p, u
 
 /* out[n] += sum_m x[m*ld + n]  (bias gradients); out must be cleared by the caller. */
 int spot_colsum_f32(const float* x, long ld, float* out, long rows, int N, hipStream_t stream);
+/* out[r*C + c] = sum_b x[(b*R + r)*ld + c]: the sum over nb clips of a [nb*R, C] block of token rows, which is what
+ * positional rows shared by every clip receive (q = k = src + pos, ltr/models/neck/transt_fusion.py:143-145).  C and ld
+ * multiples of 4. */
+int spot_batch_sum_f32(const float* x, long ld, int nb, long R, int C, float* out, hipStream_t stream);
+/* out[c] = sum over clips and pixels of x [B,C,HW]: the bias gradient of a convolution (nn.Conv2d(bias=True) in the
+ * Siamese head's towers, ltr/models/neck/ocean_fusion.py:56-85).  Fixed order, no atomics. */
+int spot_channel_sum_f32(const float* x, int B, int C, long HW, float* out, hipStream_t stream);
 
 /* ---- attention core ---------------------------------------------------------- */
 
@@ -374,6 +401,10 @@ int spot_groupdw_bwd_f32(const float* x11, const float* x12, const float* x21, c
                          float* dx11, float* dx12, float* dx21, float* dz11, float* dz12, float* dz21,
                          float* dsoftmax_partial, int planes, int hx, int wx, int hz, int wz,
                          hipStream_t stream);
+/* The last step of the line above: d_weight3[3] from dsoftmax_partial [planes,3] and weight3 (softmax mixing of
+ * GroupDW.forward, ltr/models/neck/ocean_fusion.py:217-236).  One launch, planes summed in a fixed order. */
+int spot_groupdw_weight_grad_f32(const float* dsoftmax_partial, int planes, const float* weight3, float* d_weight3,
+                                 hipStream_t stream);
 
 /* ---- Deformable convolution v1 (ltr/models/neck/dcn/src/deform_conv_cuda_kernel.cu:189-275 deformable_im2col,
  * :277-369 deformable_col2im, :371-463 deformable_col2im_coord; called from deform_conv_cuda.cpp:149-482 through

@@ -4,21 +4,20 @@ Mirror of ltr/models/loss/transt_matcher.py:10-113 and
 ltr/models/tracking/transt_criterion.py:8-181.  The reference extracts the box
 corners with four .item() calls per sample and builds index lists in numpy;
 here the positive / negative token sets are dense [B, L] masks written by one
-kernel (spot_match_masks) and every loss term is a masked reduction over all
-tokens, so nothing synchronises with the host.  The paired GIoU/IoU (forward and
-backward) is the box kernel.
+kernel (spot_match_masks) and the loss terms are masked reductions over all
+tokens inside one kernel pair (spot_transt_loss_f32 / _bwd_f32), so nothing
+synchronises with the host.
 """
 import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import lib, ops
 
 
 class TrackingMatcher(nn.Module):
-    """Returns dense maps instead of index lists: (pos [B,L] bool, neg [B,L] uint8 multiplicity or None); a negative
+    """Returns dense maps instead of index lists: (pos [B,L] uint8 0/1, neg [B,L] uint8 multiplicity or None); a negative
     token listed k times by the reference (possible only for boxes off the map) has neg = k."""
 
     @torch.no_grad()
@@ -31,7 +30,7 @@ class TrackingMatcher(nn.Module):
         pos = torch.empty((bs, num_queries), dtype=torch.uint8, device=logits.device)
         neg = torch.empty_like(pos) if tag == "sup" else None
         lib.call("spot_match_masks", ops._p(gt), bs, n, 3, ops._p(pos), ops._p(neg), ops._st())
-        return pos.bool(), neg
+        return pos, neg
 
 
 def build_matcher():
@@ -59,28 +58,14 @@ class SetCriterionTransT(nn.Module):
         gt = targets if torch.is_tensor(targets) else torch.cat([t["boxes"] for t in targets], dim=0)
         gt = gt.reshape(B, 4).float()
         pos, neg = self.matcher(outputs, gt, tag=tag)
-        num_pos = pos.sum().clamp(min=1).float()
-
-        # classification: positives are class 0, everything else the no-object class
-        target_classes = (~pos).long()
-        losses = {"loss_ce": F.cross_entropy(logits.transpose(1, 2), target_classes, self.empty_weight)}
-
-        # box regression on the positive tokens, as masked dense sums
-        tgt = gt[:, None, :].expand(B, L, 4)
-        posf = pos.float()
-        losses["loss_bbox"] = ((boxes - tgt).abs().sum(-1) * posf).sum() / num_pos
-        giou, iou = ops.GIoUPairFn.apply(boxes.reshape(-1, 4), tgt.reshape(-1, 4))
-        giou, iou = giou.view(B, L), iou.view(B, L)
-        zero = torch.zeros((), device=logits.device)
-        losses["loss_giou"] = torch.where(pos, 1 - giou, zero).sum() / num_pos
-        losses["iou"] = torch.where(pos, iou, zero).sum().detach() / num_pos
-
-        if neg is not None and ("ious_" + tag) in outputs:
-            pred = outputs["ious_" + tag].squeeze(2)
-            num_neg = neg.sum().clamp(min=1).float()
-            err = (pred - iou.detach()).abs()
-            losses["loss_iou_pred"] = torch.where(pos, err, zero).sum() / num_pos + \
-                torch.where(neg > 0, err * neg, zero).sum() / num_neg
+        pred = outputs.get("ious_" + tag) if neg is not None else None
+        # class 0 (object) for the positive tokens, the no-object class for the rest
+        ce, bbox, giou, iou, iou_pred = ops.TranstLossFn.apply(
+            logits, boxes, pred.squeeze(2) if pred is not None else None, gt, pos, neg if pred is not None else None,
+            1.0, float(self.eos_coef))
+        losses = {"loss_ce": ce, "loss_bbox": bbox, "loss_giou": giou, "iou": iou}
+        if pred is not None:
+            losses["loss_iou_pred"] = iou_pred
         return losses
 
 

@@ -139,13 +139,8 @@ __device__ __forceinline__ void dmin(float g, float p, float q, float& gp, float
     else { gp += 0.5f * g; gq += 0.5f * g; }
 }
 
-__global__ __launch_bounds__(256) void giou_bwd_kernel(const float4* __restrict__ b1, const float4* __restrict__ b2,
-                                                       const float* __restrict__ d_giou, const float* __restrict__ d_iou,
-                                                       float4* __restrict__ d_b1, int P) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const float4 p = b1[i];
-    const XYXY a = to_xyxy(p), b = to_xyxy(b2[i]);
+__device__ __forceinline__ float4 giou_grad(float4 p, float4 q, float gg, float di) {
+    const XYXY a = to_xyxy(p), b = to_xyxy(q);
     const float w1 = a.x1 - a.x0, h1 = a.y1 - a.y0;
     const float a1 = w1 * h1, a2 = (b.x1 - b.x0) * (b.y1 - b.y0);
     const float ix0 = fmaxf(a.x0, b.x0), iy0 = fmaxf(a.y0, b.y0), ix1 = fminf(a.x1, b.x1), iy1 = fminf(a.y1, b.y1);
@@ -157,8 +152,7 @@ __global__ __launch_bounds__(256) void giou_bwd_kernel(const float4* __restrict_
     const float hwr = hx1 - hx0, hhr = hy1 - hy0;
     const float hw = fmaxf(hwr, 0.f), hh = fmaxf(hhr, 0.f);
     const float area = hw * hh;
-    const float gg = d_giou ? d_giou[i] : 0.f;
-    const float gi = (d_iou ? d_iou[i] : 0.f) + gg;      // giou = iou - (area-u)/area
+    const float gi = di + gg;                            // giou = iou - (area-u)/area
     // iou = inter/u ; giou extra term -(area-u)/area = -1 + u/area
     float g_inter = gi / u;
     float g_u = -gi * inter / (u * u) + gg / area;
@@ -184,7 +178,31 @@ __global__ __launch_bounds__(256) void giou_bwd_kernel(const float4* __restrict_
     gx1 += g_a1 * h1; gx0 -= g_a1 * h1;
     gy1 += g_a1 * w1; gy0 -= g_a1 * w1;
     // xyxy -> cxcywh
-    d_b1[i] = make_float4(gx0 + gx1, gy0 + gy1, 0.5f * (gx1 - gx0), 0.5f * (gy1 - gy0));
+    return make_float4(gx0 + gx1, gy0 + gy1, 0.5f * (gx1 - gx0), 0.5f * (gy1 - gy0));
+}
+
+__global__ __launch_bounds__(256) void giou_bwd_kernel(const float4* __restrict__ b1, const float4* __restrict__ b2,
+                                                       const float* __restrict__ d_giou, const float* __restrict__ d_iou,
+                                                       float4* __restrict__ d_b1, int P) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    d_b1[i] = giou_grad(b1[i], b2[i], d_giou ? d_giou[i] : 0.f, d_iou ? d_iou[i] : 0.f);
+}
+
+// (iou, giou) of one pair of cxcywh boxes, rounded operation by operation as the element-wise reference is.
+__device__ __forceinline__ void giou_pair(float4 p, float4 q, float& io, float& gio) {
+    const XYXY a = to_xyxy(p), b = to_xyxy(q);
+    const float a1 = __fmul_rn(__fsub_rn(a.x1, a.x0), __fsub_rn(a.y1, a.y0));
+    const float a2 = __fmul_rn(__fsub_rn(b.x1, b.x0), __fsub_rn(b.y1, b.y0));
+    const float iw = fmaxf(__fsub_rn(fminf(a.x1, b.x1), fmaxf(a.x0, b.x0)), 0.f);
+    const float ih = fmaxf(__fsub_rn(fminf(a.y1, b.y1), fmaxf(a.y0, b.y0)), 0.f);
+    const float inter = __fmul_rn(iw, ih);
+    const float u = __fsub_rn(__fadd_rn(a1, a2), inter);
+    io = __fdiv_rn(inter, u);
+    const float hw = fmaxf(__fsub_rn(fmaxf(a.x1, b.x1), fminf(a.x0, b.x0)), 0.f);
+    const float hh = fmaxf(__fsub_rn(fmaxf(a.y1, b.y1), fminf(a.y0, b.y0)), 0.f);
+    const float area = __fmul_rn(hw, hh);
+    gio = __fsub_rn(io, __fdiv_rn(__fsub_rn(area, u), area));
 }
 
 // out = keep(seed,row,col) ? x / (1-p) : 0 with the mask function the GEMM epilogue uses (row = token row,
@@ -471,5 +489,181 @@ extern "C" int spot_clip_grad_norm_f32(float* grads, long n, float max_norm, flo
         clip_scale_kernel<<<2048, 256, 0, stream>>>((float4*)grads, n / 4, norm_out, max_norm);
         SPOT_CHECK_LAUNCH("clip_grad_norm(scale)");
     }
+    return SPOT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Set criterion of the transformer tracker in two launches (ltr/models/tracking/transt_criterion.py:40-109,136-170):
+// class-weighted cross entropy over every token (positives are class 0, everything else the no-object class),
+// L1 + (1 - GIoU) on the positive tokens, and the L1 of the IoU head against the detached IoU on the positive and the
+// negative tokens.  Token sets come as dense maps (spot_match_masks); the target box of a token is its clip's box.
+//   sums per workgroup: 0 w*nll, 1 w, 2 pos L1, 3 pos (1-giou), 4 pos iou, 5 pos |pred-iou|, 6 neg*|pred-iou|,
+//                       7 #pos, 8 sum of neg multiplicities
+// Partials in float, their sum in double and in a fixed order: the same bits on every run.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int LOSS_TERMS = 9;
+constexpr int LOSS_MAX_BLOCKS = 4096;
+
+__global__ __launch_bounds__(256) void transt_loss_partial_kernel(
+    const float2* __restrict__ logits, const float4* __restrict__ boxes, const float* __restrict__ iou_pred,
+    const float4* __restrict__ gt, const unsigned char* __restrict__ pos, const unsigned char* __restrict__ neg,
+    float w_obj, float w_eos, int L, long total, float* __restrict__ part) {
+    __shared__ float s[4][LOSS_TERMS];
+    float t[LOSS_TERMS];
+#pragma unroll
+    for (int k = 0; k < LOSS_TERMS; ++k) t[k] = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const bool is_pos = pos[i] != 0;
+        const float nmul = neg ? (float)neg[i] : 0.f;
+        const float2 x = logits[i];
+        const float m = fmaxf(x.x, x.y);
+        const float lse = m + logf(expf(x.x - m) + expf(x.y - m));
+        const float w = is_pos ? w_obj : w_eos;
+        t[0] += w * (lse - (is_pos ? x.x : x.y));
+        t[1] += w;
+        if (is_pos || nmul > 0.f) {
+            const float4 b = boxes[i], g = gt[i / L];
+            float io, gio;
+            giou_pair(b, g, io, gio);
+            const float err = iou_pred ? fabsf(iou_pred[i] - io) : 0.f;
+            if (is_pos) {
+                t[2] += (fabsf(b.x - g.x) + fabsf(b.y - g.y)) + (fabsf(b.z - g.z) + fabsf(b.w - g.w));
+                t[3] += 1.f - gio;
+                t[4] += io;
+                t[5] += err;
+                t[7] += 1.f;
+            }
+            if (nmul > 0.f) {
+                t[6] += err * nmul;
+                t[8] += nmul;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LOSS_TERMS; ++k) {
+        const float v = wave_sum(t[k]);
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < LOSS_TERMS)
+        part[blockIdx.x * LOSS_TERMS + threadIdx.x] =
+            (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+
+// losses = (loss_ce, loss_bbox, loss_giou, iou, loss_iou_pred); norms = (sum of class weights, max(#pos,1), max(#neg,1))
+__global__ __launch_bounds__(64) void transt_loss_finish_kernel(const float* __restrict__ part, int nblocks,
+                                                                int has_iou_head, float* __restrict__ losses,
+                                                                float* __restrict__ norms) {
+    __shared__ double tot[LOSS_TERMS];
+    if (threadIdx.x < LOSS_TERMS) {
+        double acc = 0.0;
+        for (int b = 0; b < nblocks; ++b) acc += (double)part[b * LOSS_TERMS + threadIdx.x];
+        tot[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double n_pos = tot[7] > 1.0 ? tot[7] : 1.0, n_neg = tot[8] > 1.0 ? tot[8] : 1.0;
+        losses[0] = (float)(tot[0] / tot[1]);
+        losses[1] = (float)(tot[2] / n_pos);
+        losses[2] = (float)(tot[3] / n_pos);
+        losses[3] = (float)(tot[4] / n_pos);
+        losses[4] = has_iou_head ? (float)(tot[5] / n_pos + tot[6] / n_neg) : 0.f;
+        norms[0] = (float)tot[1];
+        norms[1] = (float)n_pos;
+        norms[2] = (float)n_neg;
+    }
+}
+
+__device__ __forceinline__ float sgn(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+
+// Upstream gradients of (loss_ce, loss_bbox, loss_giou, loss_iou_pred) are read on the device (null = 0).  The IoU target
+// of the IoU head is a constant, so the head's loss sends nothing to the boxes (transt_criterion.py:92,103).
+__global__ __launch_bounds__(256) void transt_loss_bwd_kernel(
+    const float2* __restrict__ logits, const float4* __restrict__ boxes, const float* __restrict__ iou_pred,
+    const float4* __restrict__ gt, const unsigned char* __restrict__ pos, const unsigned char* __restrict__ neg,
+    float w_obj, float w_eos, const float* __restrict__ norms, const float* __restrict__ g_ce,
+    const float* __restrict__ g_bbox, const float* __restrict__ g_giou, const float* __restrict__ g_pred, int L,
+    long total, float2* __restrict__ d_logits, float4* __restrict__ d_boxes, float* __restrict__ d_pred) {
+    const float k_ce = (g_ce ? g_ce[0] : 0.f) / norms[0];
+    const float k_l1 = (g_bbox ? g_bbox[0] : 0.f) / norms[1];
+    const float k_gi = (g_giou ? g_giou[0] : 0.f) / norms[1];
+    const float k_pp = (g_pred ? g_pred[0] : 0.f) / norms[1];
+    const float k_pn = (g_pred ? g_pred[0] : 0.f) / norms[2];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const bool is_pos = pos[i] != 0;
+        const float nmul = neg ? (float)neg[i] : 0.f;
+        if (d_logits) {
+            const float2 x = logits[i];
+            const float m = fmaxf(x.x, x.y);
+            const float e0 = expf(x.x - m), e1 = expf(x.y - m), inv = 1.f / (e0 + e1);
+            const float k = k_ce * (is_pos ? w_obj : w_eos);
+            d_logits[i] = make_float2(k * (e0 * inv - (is_pos ? 1.f : 0.f)), k * (e1 * inv - (is_pos ? 0.f : 1.f)));
+        }
+        float4 db = make_float4(0.f, 0.f, 0.f, 0.f);
+        float dp = 0.f;
+        if (is_pos || nmul > 0.f) {
+            const float4 b = boxes[i], g = gt[i / L];
+            if (is_pos && d_boxes) {
+                db = giou_grad(b, g, -k_gi, 0.f);
+                db.x += k_l1 * sgn(b.x - g.x);
+                db.y += k_l1 * sgn(b.y - g.y);
+                db.z += k_l1 * sgn(b.z - g.z);
+                db.w += k_l1 * sgn(b.w - g.w);
+            }
+            if (d_pred) {
+                float io, gio;
+                giou_pair(b, g, io, gio);
+                const float sg = sgn(iou_pred[i] - io);
+                dp = (is_pos ? k_pp * sg : 0.f) + k_pn * nmul * sg;
+            }
+        }
+        if (d_boxes) d_boxes[i] = db;
+        if (d_pred) d_pred[i] = dp;
+    }
+}
+}  // namespace
+
+extern "C" long spot_transt_loss_ws_floats(void) { return (long)LOSS_MAX_BLOCKS * LOSS_TERMS; }
+
+static int loss_grid(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g > LOSS_MAX_BLOCKS ? LOSS_MAX_BLOCKS : g);
+}
+
+extern "C" int spot_transt_loss_f32(const float* logits, const float* boxes, const float* iou_pred, const float* gt,
+                                    const unsigned char* pos, const unsigned char* neg, float w_obj, float w_eos,
+                                    int B, int L, float* losses, float* norms, float* ws, hipStream_t stream) {
+    SPOT_CHECK_ARG(logits && boxes && gt && pos && losses && norms && ws, "transt_loss: null pointer");
+    SPOT_CHECK_ARG(B > 0 && L > 0, "transt_loss: bad shape B=%d L=%d", B, L);
+    SPOT_CHECK_ARG((((uintptr_t)logits & 7) | ((uintptr_t)boxes & 15) | ((uintptr_t)gt & 15)) == 0,
+                   "transt_loss: logits must be 8-byte aligned, boxes and targets 16-byte aligned");
+    const long total = (long)B * L;
+    const int grid = loss_grid(total);
+    transt_loss_partial_kernel<<<grid, 256, 0, stream>>>((const float2*)logits, (const float4*)boxes, iou_pred,
+                                                         (const float4*)gt, pos, neg, w_obj, w_eos, L, total, ws);
+    SPOT_CHECK_LAUNCH("transt_loss(partials)");
+    transt_loss_finish_kernel<<<1, 64, 0, stream>>>(ws, grid, iou_pred != nullptr, losses, norms);
+    SPOT_CHECK_LAUNCH("transt_loss(finish)");
+    return SPOT_OK;
+}
+
+extern "C" int spot_transt_loss_bwd_f32(const float* logits, const float* boxes, const float* iou_pred, const float* gt,
+                                        const unsigned char* pos, const unsigned char* neg, float w_obj, float w_eos,
+                                        const float* norms, const float* g_ce, const float* g_bbox, const float* g_giou,
+                                        const float* g_iou_pred, int B, int L, float* d_logits, float* d_boxes,
+                                        float* d_iou_pred, hipStream_t stream) {
+    SPOT_CHECK_ARG(logits && boxes && gt && pos && norms, "transt_loss_bwd: null pointer");
+    SPOT_CHECK_ARG(B > 0 && L > 0, "transt_loss_bwd: bad shape B=%d L=%d", B, L);
+    SPOT_CHECK_ARG(d_logits || d_boxes || d_iou_pred, "transt_loss_bwd: no gradient requested");
+    SPOT_CHECK_ARG(!d_iou_pred || iou_pred, "transt_loss_bwd: a gradient for the IoU head needs its predictions");
+    SPOT_CHECK_ARG((((uintptr_t)logits & 7) | ((uintptr_t)boxes & 15) | ((uintptr_t)gt & 15) | ((uintptr_t)d_logits & 7) |
+                    ((uintptr_t)d_boxes & 15)) == 0,
+                   "transt_loss_bwd: logits must be 8-byte aligned, boxes and targets 16-byte aligned");
+    const long total = (long)B * L;
+    transt_loss_bwd_kernel<<<loss_grid(total), 256, 0, stream>>>(
+        (const float2*)logits, (const float4*)boxes, iou_pred, (const float4*)gt, pos, neg, w_obj, w_eos, norms, g_ce,
+        g_bbox, g_giou, g_iou_pred, L, total, (float2*)d_logits, (float4*)d_boxes, d_iou_pred);
+    SPOT_CHECK_LAUNCH("transt_loss_bwd");
     return SPOT_OK;
 }

@@ -180,7 +180,56 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     if (wave == 0 && n < N) atomicAdd(out + n, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
+// out[r][c] = sum_b x[(b*R + r)*ld + c]: the sum over clips of a [nb*R, C] row block (what the shared positional
+// rows receive from every clip); one thread per four adjacent columns.
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ x, long ld, int nb, long R, int C4,
+                                                        float4* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * C4) return;
+    const long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < nb; ++b) {
+        const float4 v = *(const float4*)(x + ((long)b * R + r) * ld + c);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    out[i] = a;
+}
+
+// out[c] = sum over clips and pixels of x[b][c][:]: one workgroup per channel, a fixed order (no atomics).
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int B, int C, long HW,
+                                                          float* __restrict__ out) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* p = x + ((long)b * C + c) * HW;
+        for (long i = threadIdx.x; i < HW; i += 256) acc += p[i];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 }  // namespace
+
+extern "C" int spot_batch_sum_f32(const float* x, long ld, int nb, long R, int C, float* out, hipStream_t stream) {
+    SPOT_CHECK_ARG(x && out && nb > 0 && R > 0 && C > 0, "batch_sum: bad arguments");
+    SPOT_CHECK_ARG(C % 4 == 0 && ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0,
+                   "batch_sum: C=%d and the row stride must be multiples of 4, buffers 16-byte aligned", C);
+    const long n = R * (C / 4);
+    batch_sum_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(x, ld, nb, R, C / 4, (float4*)out);
+    SPOT_CHECK_LAUNCH("batch_sum");
+    return SPOT_OK;
+}
+
+extern "C" int spot_channel_sum_f32(const float* x, int B, int C, long HW, float* out, hipStream_t stream) {
+    SPOT_CHECK_ARG(x && out && B > 0 && C > 0 && HW > 0, "channel_sum: bad arguments");
+    channel_sum_kernel<<<C, 256, 0, stream>>>(x, B, C, HW, out);
+    SPOT_CHECK_LAUNCH("channel_sum");
+    return SPOT_OK;
+}
 
 extern "C" int spot_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                       float* rstd, long rows, int C, float eps, hipStream_t stream) {

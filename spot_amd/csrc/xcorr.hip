@@ -1473,3 +1473,43 @@ extern "C" int spot_groupdw_bwd_f32(const float* x11, const float* x12, const fl
     float* dzs[3] = {dz11, dz12, dz21};
     return launch_bwd(b, 3, weight3, d_out, dxs, dzs, dsoftmax_partial, planes, stream);
 }
+
+// Gradient of the three mixing logits from the per-plane sums the backward kernel leaves (GroupDW.forward mixes with
+// softmax(weight), ltr/models/neck/ocean_fusion.py:217-236): ds_k = sum over planes, dw = s * (ds - <s, ds>).
+// One workgroup, planes summed in double in a fixed order.
+namespace {
+__global__ __launch_bounds__(256) void groupdw_weight_grad_kernel(const float* __restrict__ part, int planes,
+                                                                  const float* __restrict__ weight, float* __restrict__ dw) {
+    __shared__ double red[3][256];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int p = threadIdx.x; p < planes; p += 256) {
+        a0 += (double)part[(size_t)p * 3];
+        a1 += (double)part[(size_t)p * 3 + 1];
+        a2 += (double)part[(size_t)p * 3 + 2];
+    }
+    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(weight[0], fmaxf(weight[1], weight[2]));
+        const float e0 = expf(weight[0] - m), e1 = expf(weight[1] - m), e2 = expf(weight[2] - m);
+        const float inv = 1.f / (e0 + e1 + e2);
+        const float s[3] = {e0 * inv, e1 * inv, e2 * inv};
+        const float ds[3] = {(float)red[0][0], (float)red[1][0], (float)red[2][0]};
+        const float dot = s[0] * ds[0] + s[1] * ds[1] + s[2] * ds[2];
+        for (int k = 0; k < 3; ++k) dw[k] = s[k] * (ds[k] - dot);
+    }
+}
+}  // namespace
+
+extern "C" int spot_groupdw_weight_grad_f32(const float* dsoftmax_partial, int planes, const float* weight3, float* d_weight3,
+                                            hipStream_t stream) {
+    SPOT_CHECK_ARG(dsoftmax_partial && weight3 && d_weight3 && planes > 0, "groupdw_weight_grad: bad arguments");
+    groupdw_weight_grad_kernel<<<1, 256, 0, stream>>>(dsoftmax_partial, planes, weight3, d_weight3);
+    SPOT_CHECK_LAUNCH("groupdw_weight_grad");
+    return SPOT_OK;
+}

@@ -65,6 +65,8 @@ SIGNATURES = {
     "spot_ema_lerp_i64": [vp, vp, i32, f64, vp],
     "spot_box_iou_pair_f32": [vp, vp, i32, vp, vp, vp, i32, vp],
     "spot_box_giou_pair_bwd_f32": [vp, vp, vp, vp, vp, i32, vp],
+    "spot_transt_loss_f32": [vp] * 6 + [f32, f32, i32, i32, vp, vp, vp, vp],
+    "spot_transt_loss_bwd_f32": [vp] * 6 + [f32, f32] + [vp] * 5 + [i32, i32, vp, vp, vp, vp],
     "spot_xcorr_depthwise_f32": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "spot_groupdw_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "spot_xcorr_depthwise_bwd_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
@@ -77,6 +79,9 @@ SIGNATURES = {
     "spot_clip_grad_norm_f32": [vp, i64, f32, vp, vp, vp],
     "spot_gemm_f32": [C.POINTER(GemmDesc), vp],
     "spot_colsum_f32": [vp, i64, vp, i64, i32, vp],
+    "spot_batch_sum_f32": [vp, i64, i32, i64, i32, vp, vp],
+    "spot_channel_sum_f32": [vp, i32, i32, i64, vp, vp],
+    "spot_groupdw_weight_grad_f32": [vp, i32, vp, vp, vp],
     "spot_im2col_f32": [vp, vp] + [i32] * 12 + [vp],
     "spot_col2im_f32": [vp, vp] + [i32] * 12 + [vp],
     "spot_rotate_flip_nearest_f32": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
@@ -139,6 +144,8 @@ def load():
     lib.spot_conv3x3_winograd_general_v_floats.argtypes = [i32] * 7
     lib.spot_mha_fwd_splitk_ws_floats.restype = i64
     lib.spot_mha_fwd_splitk_ws_floats.argtypes = [i32] * 4
+    lib.spot_transt_loss_ws_floats.restype = i64
+    lib.spot_transt_loss_ws_floats.argtypes = []
     lib.spot_clip_grad_norm_ws_floats.restype = i64
     lib.spot_clip_grad_norm_ws_floats.argtypes = []
     lib.spot_deform_col2im_ws_floats.restype = i64

@@ -247,6 +247,46 @@ class GIoUPairFn(_Fn):
         return out, None
 
 
+class TranstLossFn(_Fn):
+    """(loss_ce, loss_bbox, loss_giou, iou, loss_iou_pred) of the set criterion as five 0-dim tensors from two launches;
+    backward is one launch that reads the five upstream gradients on the device.  iou_pred / neg may be None (no IoU
+    head); `iou` carries no gradient (transt_criterion.py:86 reports it only)."""
+
+    @staticmethod
+    def forward(ctx, logits, boxes, iou_pred, gt, pos, neg, w_obj, w_eos):
+        logits, boxes, gt = logits.contiguous(), boxes.contiguous(), gt.contiguous()
+        iou_pred = iou_pred.contiguous() if iou_pred is not None else None
+        _chk(logits), _chk(boxes), _chk(gt), _chk(pos, torch.uint8, "pos")
+        B, L = logits.shape[:2]
+        if logits.shape != (B, L, 2) or boxes.shape != (B, L, 4) or gt.shape != (B, 4) or pos.shape != (B, L):
+            raise RuntimeError("spot_amd: set criterion expects logits [B,L,2], boxes [B,L,4], targets [B,4], pos [B,L]")
+        dev = logits.device
+        out = torch.empty((8,), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.load().spot_transt_loss_ws_floats(),), dtype=torch.float32, device=dev)
+        lib.call("spot_transt_loss_f32", _p(logits), _p(boxes), _p(iou_pred), _p(gt), _p(pos), _p(neg), float(w_obj),
+                 float(w_eos), B, L, _p(out), out.data_ptr() + 20, _p(ws), _st())
+        ctx.w = (float(w_obj), float(w_eos))
+        ctx.has_pred = iou_pred is not None
+        if _wants(ctx):
+            ctx.save_for_backward(logits, boxes, iou_pred, gt, pos, neg, out)
+        losses = tuple(out[i] for i in range(5))
+        ctx.mark_non_differentiable(losses[3])
+        return losses
+
+    @staticmethod
+    def backward(ctx, g_ce, g_bbox, g_giou, _g_iou, g_pred):
+        logits, boxes, iou_pred, gt, pos, neg, out = ctx.saved_tensors
+        B, L = logits.shape[:2]
+        need = ctx.needs_input_grad
+        d_logits = torch.empty_like(logits) if need[0] else None
+        d_boxes = torch.empty_like(boxes) if need[1] else None
+        d_pred = torch.empty_like(iou_pred) if (ctx.has_pred and need[2]) else None
+        lib.call("spot_transt_loss_bwd_f32", _p(logits), _p(boxes), _p(iou_pred), _p(gt), _p(pos), _p(neg), ctx.w[0],
+                 ctx.w[1], out.data_ptr() + 20, _p(g_ce), _p(g_bbox), _p(g_giou), _p(g_pred), B, L, _p(d_logits),
+                 _p(d_boxes), _p(d_pred), _st())
+        return d_logits, d_boxes, d_pred, None, None, None, None, None
+
+
 # ---------------------------------------------------------------------------
 # crop + pad + resize of frames
 # ---------------------------------------------------------------------------
@@ -342,9 +382,8 @@ class GroupDWFn(_Fn):
         lib.call("spot_groupdw_bwd_f32", _p(x11), _p(x12), _p(x21), _p(z11), _p(z12), _p(z21), _p(weight),
                  _p(g.contiguous()), _p(dxs[0]), _p(dxs[1]), _p(dxs[2]), _p(dzs[0]), _p(dzs[1]), _p(dzs[2]),
                  _p(part), B * Cn, hx, wx, hz, wz, _st())
-        ds = part.sum(0)
-        sw = torch.softmax(weight, 0)
-        dw = sw * (ds - (sw * ds).sum())
+        dw = torch.empty_like(weight)
+        lib.call("spot_groupdw_weight_grad_f32", _p(part), B * Cn, _p(weight), _p(dw), _st())
         return dzs[0], dzs[1], dzs[2], dxs[0], dxs[1], dxs[2], dw
 
 
@@ -556,6 +595,25 @@ def _bias_grad_buffer(sink, n, device):
     return sink if sink is not None else torch.zeros((n,), dtype=torch.float32, device=device)
 
 
+def batch_sum(x2, R):
+    """[nb*R, C] token rows (a column window of a wider buffer is fine) -> [R, C] summed over the nb clips."""
+    M, Cn = x2.shape
+    if M == R:
+        return x2
+    out = torch.empty((R, Cn), dtype=torch.float32, device=x2.device)
+    lib.call("spot_batch_sum_f32", _p(x2), x2.stride(0), M // R, R, Cn, _p(out), _st())
+    return out
+
+
+def channel_sum(x4):
+    """[B,C,H,W] -> [C] (the bias gradient of a convolution)."""
+    x4 = x4.contiguous()
+    B, Cn, H, W = x4.shape
+    out = torch.empty((Cn,), dtype=torch.float32, device=x4.device)
+    lib.call("spot_channel_sum_f32", _p(x4), B, Cn, H * W, _p(out), _st())
+    return out
+
+
 def colsum(x2, out=None):
     M, N = x2.shape
     if out is None:
@@ -564,49 +622,96 @@ def colsum(x2, out=None):
     return out
 
 
+def _linear_param_grads(pW, pb, need_W, need_b, dy2, x2):
+    """(dW, db) of y = x W^T + b, written into the parameters' slices of the flat gradient buffer when they have one
+    (then None is returned for that gradient); the bias gradient rides on the weight-gradient launch."""
+    dW = db = None
+    want_b = pb is not None and need_b
+    gb = _sink(pb) if want_b else None
+    if want_b and need_W:
+        db = _bias_grad_buffer(gb, pW.shape[0], dy2.device)
+    if need_W:
+        gW = _sink(pW)
+        dW = linear_wgrad(dy2, x2, out=gW, accumulate=gW is not None, bias_out=db)
+        if gW is not None:
+            dW = None
+            _sink_done(pW)
+    if want_b:
+        if db is None:
+            db = colsum(dy2, out=gb)
+        if gb is not None:
+            db = None
+            _sink_done(pb)
+    return dW, db
+
+
 class LinearFn(_Fn):
-    """nn.Linear (+ fused ReLU) on [..., K] inputs."""
+    """nn.Linear on [..., K] inputs."""
 
     @staticmethod
-    def forward(ctx, x, W, b, relu):
+    def forward(ctx, x, W, b):
         x2 = _view2d(x.contiguous())
-        y = linear_fwd(x2, W, b, relu=relu)
-        ctx.relu = relu
-        ctx.save_for_backward(x2, W, y if relu else None)
+        y = linear_fwd(x2, W, b)
+        ctx.save_for_backward(x2, W)
         ctx.params = (W, b)
         _sink_expect(W if ctx.needs_input_grad[1] else None, b if ctx.needs_input_grad[2] else None)
         return y.view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, W, y = ctx.saved_tensors
+        x2, W = ctx.saved_tensors
         pW, pb = ctx.params
         dy2 = _view2d(dy.contiguous())
-        if ctx.relu:
-            dy2 = torch.where(y > 0, dy2, torch.zeros((), device=dy2.device))
         dx = linear_dgrad(dy2, W) if ctx.needs_input_grad[0] else None
-        dW = db = None
-        want_b = pb is not None and ctx.needs_input_grad[2]
-        gb = _sink(pb) if want_b else None
-        if want_b and ctx.needs_input_grad[1]:          # bias gradient rides on the weight-gradient launch
-            db = _bias_grad_buffer(gb, W.shape[0], dy2.device)
-        if ctx.needs_input_grad[1]:
-            gW = _sink(pW)
-            dW = linear_wgrad(dy2, x2, out=gW, accumulate=gW is not None, bias_out=db)
-            if gW is not None:
-                dW = None
-                _sink_done(pW)
-        if want_b:
-            if db is None:
-                db = colsum(dy2, out=gb)
-            if gb is not None:
-                db = None
-                _sink_done(pb)
-        return (dx.view(*dy.shape[:-1], W.shape[1]) if dx is not None else None), dW, db, None
+        dW, db = _linear_param_grads(pW, pb, ctx.needs_input_grad[1], ctx.needs_input_grad[2], dy2, x2)
+        return (dx.view(*dy.shape[:-1], W.shape[1]) if dx is not None else None), dW, db
 
 
-def linear(x, W, b=None, relu=False):
-    return LinearFn.apply(x, W, b, relu)
+class MLPFn(_Fn):
+    """Linear -> ReLU -> ... -> Linear on [..., K] inputs (the prediction heads, ltr/models/tracking/transt_model.py:296-310).
+    ReLU runs in each GEMM's epilogue; in backward its derivative is the mask operand of the next layer's input-gradient
+    GEMM (zero where the stored activation is <= 0), so no element-wise pass exists in either direction."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        n = len(params) // 2
+        hs = [_view2d(x.contiguous())]
+        for i in range(n):
+            hs.append(linear_fwd(hs[-1], params[2 * i], params[2 * i + 1], relu=i < n - 1))
+        ctx.params = params
+        if _wants(ctx):
+            ctx.save_for_backward(*hs[:-1])
+        for i in range(n):
+            _sink_expect(params[2 * i] if ctx.needs_input_grad[1 + 2 * i] else None,
+                         params[2 * i + 1] if (params[2 * i + 1] is not None and ctx.needs_input_grad[2 + 2 * i]) else None)
+        return hs[-1].view(*x.shape[:-1], params[2 * n - 2].shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        hs = ctx.saved_tensors
+        params = ctx.params
+        n = len(params) // 2
+        need = ctx.needs_input_grad
+        grads = [None] * (2 * n)
+        d = _view2d(dy.contiguous())
+        for i in range(n - 1, -1, -1):
+            W, b = params[2 * i], params[2 * i + 1]
+            grads[2 * i], grads[2 * i + 1] = _linear_param_grads(W, b, need[1 + 2 * i], need[2 + 2 * i], d, hs[i])
+            if i > 0:
+                d = linear_dgrad(d, W, mask=hs[i])
+            else:
+                d = linear_dgrad(d, W) if need[0] else None
+        dx = d.view(*dy.shape[:-1], params[0].shape[1]) if d is not None else None
+        return (dx,) + tuple(grads)
+
+
+def linear(x, W, b=None):
+    return LinearFn.apply(x, W, b)
+
+
+def mlp(x, layers):
+    """layers: the nn.Linear modules in order; ReLU between them."""
+    return MLPFn.apply(x, *[t for l in layers for t in (l.weight, l.bias)])
 
 
 class FFNFn(_Fn):
@@ -849,7 +954,7 @@ class ConvIm2colFn(_Fn):
         (pw,) = ctx.params
         B, Ci, H, W, Co, kh, kw, stride, pad, dh, dw_, K, Kpad, N, Np = ctx.geo
         dev = dy.device
-        dbias = dy.sum((0, 2, 3)) if ctx.needs_input_grad[5] else None
+        dbias = channel_sum(dy) if ctx.needs_input_grad[5] else None
         if Np != N:
             dyp = torch.zeros((B, Co, Np), dtype=torch.float32, device=dev)
             dyp[:, :, :N] = dy.reshape(B, Co, N)
@@ -1016,7 +1121,7 @@ class Conv3x3GenFn(_Fn):
         dev = dy.device
         dx = dw = dbias = None
         if ctx.needs_input_grad[2]:
-            dbias = dy.sum((0, 2, 3))
+            dbias = channel_sum(dy)
         if ctx.needs_input_grad[0]:
             Ho, Wo = dy.shape[2:]
             dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=dev)
@@ -1543,8 +1648,7 @@ class MHAFn(_Fn):
             linear_wgrad(dqkv, xq2, out=d_in_w, accumulate=True, bias_out=d_in_b)
             # (x + pos) W^T: the pos part of dW is (sum over clips of dq|dk)^T pos
             R = pos_q.shape[0]
-            dqk_sum = dqkv[:, :2 * Cn].reshape(-1, R, 2 * Cn).sum(0) if R != dqkv.shape[0] else dqkv[:, :2 * Cn]
-            linear_wgrad(dqk_sum.contiguous(), pos_q, out=d_in_w[:2 * Cn], accumulate=True)
+            linear_wgrad(batch_sum(dqkv[:, :2 * Cn], R), pos_q, out=d_in_w[:2 * Cn], accumulate=True)
         else:
             dq = torch.empty_like(qkv)
             dkv = torch.empty_like(kv)
@@ -1558,10 +1662,8 @@ class MHAFn(_Fn):
             linear_wgrad(dq, xq2, out=d_in_w[:Cn], accumulate=True, bias_out=d_in_b[:Cn])
             linear_wgrad(dkv, xkv2, out=d_in_w[Cn:], accumulate=True, bias_out=d_in_b[Cn:])
             Rq, Rk = pos_q.shape[0], pos_k.shape[0]
-            dq_sum = dq.reshape(-1, Rq, Cn).sum(0) if Rq != dq.shape[0] else dq
-            dk_sum = dkv[:, :Cn].reshape(-1, Rk, Cn).sum(0) if Rk != dkv.shape[0] else dkv[:, :Cn]
-            linear_wgrad(dq_sum.contiguous(), pos_q, out=d_in_w[:Cn], accumulate=True)
-            linear_wgrad(dk_sum.contiguous(), pos_k, out=d_in_w[Cn:2 * Cn], accumulate=True)
+            linear_wgrad(batch_sum(dq, Rq), pos_q, out=d_in_w[:Cn], accumulate=True)
+            linear_wgrad(batch_sum(dkv[:, :Cn], Rk), pos_k, out=d_in_w[Cn:2 * Cn], accumulate=True)
         _sink_done(*ctx.params)
         pg = [None if sk is not None else g for sk, g in zip(sinks, (d_in_w, d_in_b, d_out_w, d_out_b))]
         # self-attention: xq and xkv are the same tensor, the whole gradient goes to xq

@@ -108,9 +108,7 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList(_LinearParams(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
     def forward(self, x):
-        for i, layer in enumerate(self.layers):
-            x = ops.linear(x, layer.weight, layer.bias, relu=i < self.num_layers - 1)
-        return x
+        return ops.mlp(x, self.layers)
 
 
 class _Conv1x1Params(nn.Module):

@@ -938,3 +938,98 @@ def test_matcher_masks_and_criterion_golden(golden, name, seed):
         for k, v in o.items():
             ref = g["grad_" + k]
             np.testing.assert_allclose(v.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-6 * float(np.abs(ref).max()), err_msg=k)
+
+
+# --------------------------------------------------------------------------- set criterion, heads, small reductions
+@pytest.mark.parametrize("tag", ["sup", "unsup"])
+def test_set_criterion_kernels_against_oracle(ops, tag):
+    """spot_transt_loss_f32 / _bwd_f32 against the oracle's criterion (autograd on the CPU): every loss term and the
+    gradients of a weighted total, with zero-size boxes on tokens outside both sets (their GIoU is NaN and must not leak)
+    and a prediction that equals its target exactly (sign(0) = 0)."""
+    from spot_amd.criterion import transt_loss
+    from spot_amd.synthetic import Settings
+    B, L = 6, 1024
+    rng = np.random.default_rng(5)
+    logits = rng.uniform(-3, 3, (B, L, 2)).astype(np.float32)
+    boxes = rng.uniform(0.05, 0.7, (B, L, 4)).astype(np.float32)
+    ious = rng.uniform(0, 1, (B, L, 1)).astype(np.float32)
+    gt = np.stack([rng.uniform(0.3, 0.7, B), rng.uniform(0.3, 0.7, B), rng.uniform(0.05, 0.5, B),
+                   rng.uniform(0.05, 0.5, B)], 1).astype(np.float32)
+    pos_o, neg_o = O.matcher_masks(gt, L, with_neg=True)
+    outside = ~(pos_o | (neg_o > 0))
+    boxes[outside, 2:] = 0.0
+    boxes[0, np.flatnonzero(pos_o[0])[0]] = gt[0]                       # |box - target| = 0 on one positive token
+    wd = Settings().weight_dict
+    ref_in = [T(a).requires_grad_() for a in (logits, boxes, ious)]
+    ref = O.criterion(ref_in[0], ref_in[1], ref_in[2] if tag == "sup" else None, T(gt), tag=tag)
+    sum(ref[k] * wd[k + "_" + tag] for k in ref if k + "_" + tag in wd).backward()
+    crit = transt_loss(Settings()).to(DEV)
+    o = {"logits_" + tag: G(logits).requires_grad_(), "boxes_" + tag: G(boxes).requires_grad_()}
+    if tag == "sup":
+        o["ious_" + tag] = G(ious).requires_grad_()
+    got = crit(o, G(gt), tag=tag)
+    assert set(got) == set(ref)
+    for k in ref:
+        np.testing.assert_allclose(got[k].item(), ref[k].item(), rtol=1e-5, err_msg=k)
+    assert not got["iou"].requires_grad
+    sum(got[k] * wd[k + "_" + tag] for k in got if k + "_" + tag in wd).backward()
+    for name, r in zip(("logits_", "boxes_", "ious_"), ref_in):
+        if name + tag not in o:
+            continue
+        want = r.grad.numpy()
+        np.testing.assert_allclose(o[name + tag].grad.cpu().numpy(), want, rtol=1e-4, atol=1e-6 * float(np.abs(want).max()),
+                                   err_msg=name)
+    again = crit({k: v.detach() for k, v in o.items()}, G(gt), tag=tag)
+    assert all(torch.equal(again[k], got[k]) for k in got)               # fixed reduction order: the same bits
+
+
+def test_mlp_head_against_torch(ops):
+    """Linear-ReLU-Linear-ReLU-Linear through MLPFn (ReLU in the GEMM epilogues, its derivative as the mask operand of the
+    input-gradient GEMMs) against torch on the CPU, with pre-activations that hit zero exactly."""
+    torch.manual_seed(3)
+    lin = [torch.nn.Linear(256, 256), torch.nn.Linear(256, 256), torch.nn.Linear(256, 4)]
+    with torch.no_grad():
+        lin[0].weight[:7].zero_(), lin[0].bias[:7].zero_()               # seven hidden units sit at exactly 0
+    x = torch.randn(3, 130, 256)
+    xr = x.clone().requires_grad_()
+    h = xr
+    for i, l in enumerate(lin):
+        h = l(h)
+        if i < 2:
+            h = torch.relu(h)
+    dy = torch.randn_like(h)
+    h.backward(dy)
+    dev = [torch.nn.Linear(l.in_features, l.out_features).to(DEV) for l in lin]
+    for d, l in zip(dev, lin):
+        d.load_state_dict(l.state_dict())
+    xg = x.to(DEV).requires_grad_()
+    y = ops.mlp(xg, dev)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), h.detach().numpy(), rtol=1e-4, atol=1e-5)
+    y.backward(dy.to(DEV))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5)
+    for d, l in zip(dev, lin):
+        np.testing.assert_allclose(d.weight.grad.cpu().numpy(), l.weight.grad.numpy(), rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(d.bias.grad.cpu().numpy(), l.bias.grad.numpy(), rtol=1e-4, atol=2e-4)
+    with torch.no_grad():
+        assert torch.equal(ops.mlp(xg, dev), y)
+    lone = ops.linear(xg.detach().requires_grad_(), dev[0].weight, dev[0].bias)
+    np.testing.assert_allclose(lone.detach().cpu().numpy(), lin[0](x).detach().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_batch_channel_and_mixing_weight_reductions(ops):
+    rng = np.random.default_rng(9)
+    wide = G(rng.standard_normal((5 * 24, 96)).astype(np.float32))
+    win = wide[:, 32:64]                                                  # a column window with the wide row stride
+    np.testing.assert_allclose(ops.batch_sum(win, 24).cpu().numpy(), win.reshape(5, 24, 32).sum(0).cpu().numpy(),
+                               rtol=1e-6, atol=1e-6)
+    assert ops.batch_sum(win, 120) is win
+    x4 = G(rng.standard_normal((3, 7, 5, 9)).astype(np.float32))
+    np.testing.assert_allclose(ops.channel_sum(x4).cpu().numpy(), x4.sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # GroupDW mixing logits: gradient through softmax of the per-plane sums
+    part, w = rng.standard_normal((300, 3)).astype(np.float32), np.array([0.3, -1.2, 0.8], np.float32)
+    wt = T(w).requires_grad_()
+    (torch.softmax(wt, 0) * T(part).sum(0)).sum().backward()
+    dw, part_d, w_d = torch.empty(3, device=DEV), G(part), G(w)         # named: the launch reads them after this line
+    from spot_amd import lib
+    lib.call("spot_groupdw_weight_grad_f32", ops._p(part_d), 300, ops._p(w_d), ops._p(dw), ops._st())
+    np.testing.assert_allclose(dw.cpu().numpy(), wt.grad.numpy(), rtol=1e-5, atol=1e-6)
