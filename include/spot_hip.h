@@ -322,6 +322,12 @@ int spot_channel_sum_f32(const float* x, int B, int C, long HW, float* out, hipS
 
 /* ---- attention core ---------------------------------------------------------- */
 
+/* LIMIT of every entry point in this section: head_dim == 32, i.e. d_model = 32 * nhead.  That is the one geometry the
+ * reference's settings use (hidden_dim 256, nheads 8: ltr/train_settings/spot/spot_transt_002.py:84-86, _003.py:84-86,
+ * _003_got10k.py:84-86, _005.py:84-86); one head's 32 channels are exactly one matrix-instruction tile, which the
+ * register layout of the kernels is built on.  Any other head_dim (the reference's constructor default d_model 512 with
+ * 8 heads gives 64) returns SPOT_ERR_ARG with a message (spot_last_error); nothing is computed and no other path is taken. */
+
 /* softmax(scale * Q K^T + key_padding_mask) V per head, the middle of nn.MultiheadAttention as called at
  * ltr/models/neck/transt_fusion.py:145-148,212-213,218-219,223-230.  q [B,Lq,nhead*32] with row stride ldq
  * (so q/k/v may be column windows of a packed projection buffer), k,v [B,Lk,nhead*32], out [B,Lq,nhead*32];

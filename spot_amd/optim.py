@@ -8,6 +8,16 @@ unchanged), same update rule.  All parameters must live in one ``ParamArena`` wi
 attached (the trainer arranges that); the first and second moments are two more flat buffers.
 torch's foreach AdamW needs ~2 ms for the 23 M parameters (a handful of multi-tensor launches
 per group, each streaming the buffers again); this is one 650 MB stream (~0.15 ms).
+
+Differences from torch.optim.AdamW that a caller can observe:
+  * every parameter handed in must require a gradient (a frozen one is rejected); a parameter that receives no
+    gradient in a step is updated with gradient zero (it still decays and its moments shrink), where torch skips
+    parameters whose .grad is None;
+  * one step counter for all parameters: a checkpoint whose per-parameter steps differ is rejected;
+  * the update itself is deterministic, but the gradients it consumes are summed by split-reduction GEMMs and attention
+    kernels with float atomics, so two runs of the same step agree to rounding, not bit for bit.
+state_dict() is torch's layout (per-parameter step / exp_avg / exp_avg_sq, views of the flat buffers), so checkpoints
+travel in both directions between this class and torch.optim.AdamW.
 """
 import ctypes as C
 import math
@@ -38,7 +48,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if arena.grad_flat is None:
             arena.attach_grads()
         self.arena = arena
-        offset_of = {id(t): (o, t.numel()) for (k, t), o in zip(arena.f32, arena.offsets)}
+        offset_of = self._offset_of = {id(t): (o, t.numel()) for (k, t), o in zip(arena.f32, arena.offsets)}
         first = self.param_groups[0]
         chunks = []
         for gi, group in enumerate(self.param_groups):
@@ -47,6 +57,9 @@ class FlatAdamW(torch.optim.Optimizer):
             for p in group["params"]:
                 if id(p) not in offset_of:
                     raise ValueError("FlatAdamW: every parameter must live in the given ParamArena")
+                if not p.requires_grad:
+                    raise ValueError("FlatAdamW: a parameter with requires_grad=False was handed in; leave frozen "
+                                     "parameters out of the groups (they would decay and drift)")
                 off, n = offset_of[id(p)]
                 for s in range(0, n, self.CHUNK):
                     chunks.append((off + s, min(self.CHUNK, n - s), gi))
@@ -80,15 +93,53 @@ class FlatAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
 
+    def _moment_views(self):
+        """(exp_avg, exp_avg_sq) views per parameter, in the order torch numbers them in a state dict."""
+        out = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                off, n = self._offset_of[id(p)]
+                out.append((self.exp_avg[off:off + n].view_as(p), self.exp_avg_sq[off:off + n].view_as(p)))
+        return out
+
     def state_dict(self):
         sd = super().state_dict()
-        sd["flat"] = {"step": self._step, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
+        if self._step > 0:
+            step = torch.tensor(float(self._step))
+            sd["state"] = {i: {"step": step.clone(), "exp_avg": m, "exp_avg_sq": v}
+                           for i, (m, v) in enumerate(self._moment_views())}
         return sd
 
+    @torch.no_grad()
     def load_state_dict(self, state_dict):
-        flat = state_dict.pop("flat", None)
-        super().load_state_dict(state_dict)
+        """Accepts what state_dict() returns, what torch.optim.AdamW saves for the same groups (the reference's
+        checkpoints), and this class's older {"flat": ...} form.  The caller's dict is left as it was."""
+        sd = dict(state_dict)
+        flat = sd.pop("flat", None)
+        state = sd.get("state") or {}
+        sd["state"] = {}
+        super().load_state_dict(sd)
         if flat is not None:
             self._step = int(flat["step"])
             self.exp_avg.copy_(flat["exp_avg"])
             self.exp_avg_sq.copy_(flat["exp_avg_sq"])
+            return
+        self.exp_avg.zero_(), self.exp_avg_sq.zero_()
+        self._step = 0
+        if not state:
+            return
+        views = self._moment_views()
+        missing = [i for i in range(len(views)) if i not in state]
+        if missing:
+            raise ValueError("FlatAdamW.load_state_dict: no state for parameters %s (a checkpoint of an optimizer that "
+                             "skipped them?)" % missing[:8])
+        steps = {int(float(state[i]["step"])) for i in range(len(views))}
+        if len(steps) != 1:
+            raise ValueError("FlatAdamW.load_state_dict: per-parameter step counts differ (%s); this optimizer keeps one"
+                             % sorted(steps)[:8])
+        if any(state[i].get("max_exp_avg_sq") is not None for i in range(len(views))):
+            raise ValueError("FlatAdamW.load_state_dict: amsgrad state is not supported")
+        for i, (m, v) in enumerate(views):
+            m.copy_(state[i]["exp_avg"])
+            v.copy_(state[i]["exp_avg_sq"])
+        self._step = steps.pop()

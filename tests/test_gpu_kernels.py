@@ -659,6 +659,62 @@ def test_flat_adamw_matches_torch_adamw(ops):
     assert torch.equal(before, arena.flat)
 
 
+def test_flat_adamw_exchanges_checkpoints_with_torch_adamw(ops):
+    """A torch.optim.AdamW state dict (what the reference's checkpoints hold) loads into FlatAdamW with its moments and
+    step, the caller's dict is left alone, the next step matches torch's, and the state dict FlatAdamW writes loads back
+    into torch.optim.AdamW.  Frozen parameters and diverging per-parameter steps are refused."""
+    import copy
+    from spot_amd.arena import ParamArena
+    from spot_amd.optim import FlatAdamW
+
+    def make():
+        torch.manual_seed(6)
+        return torch.nn.Sequential(torch.nn.Linear(5, 9), torch.nn.BatchNorm1d(9), torch.nn.Linear(9, 301)).to(DEV)
+
+    def grads(models, step):
+        for m in models:
+            for n, p in m.named_parameters():
+                g = G(det_input(n, tuple(p.shape), 30 + step, -1, 1))
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+
+    a, b = make(), make()
+    ob = torch.optim.AdamW(b.parameters(), lr=2e-3, weight_decay=1e-2)
+    for step in range(2):
+        grads([b], step)
+        ob.step()
+    a.load_state_dict(b.state_dict())
+    arena = ParamArena(a, with_grads=True)
+    oa = FlatAdamW(a.parameters(), arena, lr=2e-3, weight_decay=1e-2)
+    ckpt = ob.state_dict()
+    keys_before = (set(ckpt), set(ckpt["state"]))
+    oa.load_state_dict(ckpt)
+    assert (set(ckpt), set(ckpt["state"])) == keys_before
+    assert oa._step == 2
+    grads([a, b], 2)
+    oa.step(), ob.step()
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=n)
+    # and back: torch's optimizer continues from FlatAdamW's state
+    c = make()
+    c.load_state_dict(a.state_dict())
+    oc = torch.optim.AdamW(c.parameters(), lr=2e-3, weight_decay=1e-2)
+    oc.load_state_dict(copy.deepcopy(oa.state_dict()))
+    grads([a, c], 3)
+    oa.step(), oc.step()
+    for (n, pa), (_, pc) in zip(a.named_parameters(), c.named_parameters()):
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pc.detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=n)
+    bad = copy.deepcopy(ob.state_dict())
+    bad["state"][0]["step"] = torch.tensor(7.0)
+    with pytest.raises(ValueError, match="step counts differ"):
+        oa.load_state_dict(bad)
+    a[0].bias.requires_grad_(False)
+    with pytest.raises(ValueError, match="requires_grad=False"):
+        FlatAdamW(a.parameters(), arena, lr=1e-3)
+
+
 @pytest.mark.parametrize("B,Ci,Co,H,W,stride", [(3, 64, 256, 16, 16, 1), (2, 256, 64, 8, 8, 1), (2, 96, 40, 6, 6, 1),
                                                 (2, 128, 256, 16, 16, 2)])
 def test_conv1x1_as_gemm_vs_torch(ops, B, Ci, Co, H, W, stride):
