@@ -208,6 +208,11 @@ typedef struct spot_gemm_desc {
     float* rowsum;       /* [M] or null: rowsum[m] += sum_k opA(A)[m][k], added atomically (clear it first).  Only with
                           * transA = transB = 1, batch = 1: the weight-gradient call dW = dY^T X, where this is the bias
                           * gradient sum_rows dY (the sum nn.Linear's backward takes separately) */
+    int precision;       /* 0 = exact fp32 products (the product path).  1 = "bf16x3", an experiment: each operand is cut
+                          * into three bf16 pieces (exactly) and six of the nine piece products run on the bf16 matrix
+                          * instruction with fp32 accumulation; error per product below 2^-23 |a||b|.  Only transA =
+                          * transB = 0, K % 32 == 0, M % 128 == 0, N % 128 == 0, aligned operands, no split-K;
+                          * anything else is refused */
 } spot_gemm_desc;
 
 int spot_gemm_f32(const spot_gemm_desc* desc /* host */, hipStream_t stream);

@@ -28,6 +28,32 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- "bf16x3" products (precision = 1, an experiment kept apart from the exact path) ---------------------------------
+// An fp32 value is cut, by truncation, into three bf16 pieces that sum to it exactly (8 + 8 + 8 mantissa bits):
+//   hi = x & 0xffff0000, mid = (x - hi) & 0xffff0000, lo = (x - hi) - mid   (lo has at most 8 significant bits).
+// a*b is then taken as hi*hi' + hi*mid' + mid*hi' + hi*lo' + lo*hi' + mid*mid' on v_mfma_f32_32x32x16_bf16 (each
+// product exact in the fp32 accumulator); the three dropped terms are below 2^-23 |a||b|.  The pieces are made once per
+// element, when a tile goes from registers to LDS, and LDS holds three bf16 planes per operand:
+//   plane p, row r, k: byte p*PLANE + r*B3_ROW + 2k,  B3_ROW = 80 (64 bytes of k + 16 pad: 16-byte fragment reads of
+//   32 consecutive rows fall on distinct banks).  k-contiguous operands only (A[m][k], B[n][k]: the forward of nn.Linear).
+constexpr int B3_ROW = 80;
+__device__ __forceinline__ void split3(float4 v, uint2& hi, uint2& mid, uint2& lo) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned a[4], b[4], c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = __float_as_uint(x[j]);
+        const float r = x[j] - __uint_as_float(a[j] & 0xffff0000u);
+        b[j] = __float_as_uint(r);
+        c[j] = __float_as_uint(r - __uint_as_float(b[j] & 0xffff0000u));
+    }
+    // v_perm_b32: the upper halves of two dwords side by side, the first value in the lower half
+    hi = make_uint2(__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u));
+    mid = make_uint2(__builtin_amdgcn_perm(b[1], b[0], 0x07060302u), __builtin_amdgcn_perm(b[3], b[2], 0x07060302u));
+    lo = make_uint2(__builtin_amdgcn_perm(c[1], c[0], 0x07060302u), __builtin_amdgcn_perm(c[3], c[2], 0x07060302u));
+}
 
 // TS = MFMA tiles per wave along m and along n: 2 -> 128x128 workgroup tile, 1 -> 64x64
 constexpr int BK = 32;
@@ -58,6 +84,7 @@ struct GemmArgs {
     const float* residual; long ldres; long strideRes;
     int cvec;                         // every epilogue operand allows 16-byte accesses
     int fast;                         // operands allow the unguarded interior-tile loader (see gemm_kernel)
+    int precision;                    // 0 exact fp32, 1 bf16x3
     unsigned drop_thr, drop_seed; float drop_scale;   // dropout after relu, before residual (0 = off)
     float* rowsum;                    // [M] += sum_k opA(A)[m][k] (atomic), or null
     // inference-mode BatchNorm over the rows (output channels of a 1x1 convolution), or bn_gamma = null:
@@ -126,12 +153,14 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int g, in
 
 // ROWSUM: the workgroups of the first tile column also add the row sums of opA(A) into g.rowsum (the bias
 // gradient of a linear layer when A is the transposed output gradient: its tiles pass through here anyway).
-template <int LA, int LB, bool ALIGNED, int TS, bool ROWSUM>   // LA: 1 = MK (k-contiguous), 0 = KM;  LB: 1 = NK, 0 = KN
-__global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) {
+// PREC: 0 = exact fp32 products, 1 = bf16x3 (interior tiles of k-contiguous operands only; the host checks)
+template <int LA, int LB, bool ALIGNED, int TS, bool ROWSUM, int PREC = 0>   // LA: 1 = MK (k-contiguous), 0 = KM;  LB: 1 = NK, 0 = KN
+__global__ __launch_bounds__(256, PREC ? (TS == 2 ? 2 : 4) : (TS == 2 ? 3 : 6)) void gemm_kernel(GemmArgs g) {
     using T = Tile<TS>;
     constexpr int BM = T::BM, BN = T::BN, NL = T::NL, MPAD = T::MPAD, TILE_F = T::TILE_F, CPAD = T::CPAD;
     constexpr int RSH = T::RSH, RMASK = (1 << RSH) - 1, WT = 32 * TS;   // WT: rows (cols) of a wave's sub-tile
-    __shared__ __attribute__((aligned(16))) float lds[2 * TILE_F];
+    constexpr int B3_PLANE = BM * B3_ROW;                               // bytes per bf16 plane of one operand
+    __shared__ __attribute__((aligned(16))) float lds[PREC ? 6 * B3_PLANE / 4 : 2 * TILE_F];
     float* const As = lds;
     float* const Bs = lds + TILE_F;
 
@@ -249,8 +278,102 @@ __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void gemm_kernel(GemmArgs g) 
             }
         }
     };
-    if (fast) k_loop(std::true_type{});
-    else k_loop(std::false_type{});
+    // bf16x3 main loop.  LDS holds tile kt (bf16 pieces); one register set holds the raw fp32 tile kt+1, the other
+    // has the loads of tile kt+2 in flight.  Between the two barriers of an iteration a wave issues its 48 matrix
+    // instructions and, in their shadow, cuts tile kt+1 into pieces and writes them to LDS (the fragments of tile kt
+    // are all in registers by then), then re-issues that register set's loads for tile kt+3.  Past the last k tile the
+    // loader stays on it: a duplicate tile is staged and never read.
+    auto k_loop_bf16x3 = [&]() {
+        unsigned char* const Ab = reinterpret_cast<unsigned char*>(lds);
+        unsigned char* const Bb = Ab + 3 * B3_PLANE;
+        float4 ra[NL], rb[NL];
+        int left = kt1 - kt0 - 1;                      // tiles after the one the loader points at
+        auto fetch_next = [&](float4 (&da)[NL], float4 (&db)[NL]) {
+            const float* Ap = A + fseg * g.segA + fkin;
+            const float* Bp = B + fseg * g.segB + fkin;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) da[i] = *reinterpret_cast<const float4*>(Ap + offA[i]);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) db[i] = *reinterpret_cast<const float4*>(Bp + offB[i]);
+            const int adv = left > 0, nk = fkin + BK, wrap = nk >= g.kseg;
+            left -= adv;
+            fkin = adv ? (wrap ? 0 : nk) : fkin;
+            fseg += adv & wrap;
+        };
+        auto stage = [&](const float4 (&da)[NL], const float4 (&db)[NL]) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int f = tid + 256 * i, at = (f >> 3) * B3_ROW + ((f & 7) << 3);
+                uint2 p0, p1, p2;
+                split3(da[i], p0, p1, p2);
+                *reinterpret_cast<uint2*>(Ab + at) = p0;
+                *reinterpret_cast<uint2*>(Ab + B3_PLANE + at) = p1;
+                *reinterpret_cast<uint2*>(Ab + 2 * B3_PLANE + at) = p2;
+                split3(db[i], p0, p1, p2);
+                *reinterpret_cast<uint2*>(Bb + at) = p0;
+                *reinterpret_cast<uint2*>(Bb + B3_PLANE + at) = p1;
+                *reinterpret_cast<uint2*>(Bb + 2 * B3_PLANE + at) = p2;
+            }
+        };
+        auto body = [&](float4 (&xa)[NL], float4 (&xb)[NL]) {
+            // lane half h holds k = 16 gg + 8h .. + 7 of its row on both operands
+            bf16x8 a[2][TS][3], b[2][TS][3];
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+#pragma unroll
+                for (int t = 0; t < TS; ++t)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        a[gg][t][p] = *reinterpret_cast<const bf16x8*>(Ab + p * B3_PLANE + (wm * WT + t * 32 + l31) * B3_ROW + gg * 32 + h * 16);
+#pragma unroll
+                for (int u = 0; u < TS; ++u)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        b[gg][u][p] = *reinterpret_cast<const bf16x8*>(Bb + p * B3_PLANE + (wn * WT + u * 32 + l31) * B3_ROW + gg * 32 + h * 16);
+            }
+            __syncthreads();                           // every wave holds its fragments: LDS may be overwritten
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                for (int t = 0; t < TS; ++t)
+#pragma unroll
+                    for (int u = 0; u < TS; ++u) {
+                        // smallest terms first
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gg][t][1], b[gg][u][1], acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gg][t][2], b[gg][u][0], acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gg][t][0], b[gg][u][2], acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gg][t][1], b[gg][u][0], acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gg][t][0], b[gg][u][1], acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gg][t][0], b[gg][u][0], acc[t][u], 0, 0, 0);
+                    }
+            stage(xa, xb);
+            fetch_next(xa, xb);
+            // issue order between the barriers: one matrix instruction, then a few of the vector / LDS-store
+            // instructions of the staging, so that they run while the matrix pipe is busy
+#pragma unroll
+            for (int i = 0; i < 12 * TS * TS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, TS == 2 ? 4 : 8, 0);
+                if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, TS == 2 ? 1 : 2, 0);
+            }
+            __syncthreads();                           // the staged tile is visible
+        };
+        fetch_next(sa, sb);
+        stage(sa, sb);
+        fetch_next(sa, sb);
+        fetch_next(ra, rb);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            body(sa, sb);
+            if (kt + 1 < kt1) body(ra, rb);
+        }
+    };
+    if constexpr (PREC == 1) {
+        k_loop_bf16x3();
+    } else {
+        if (fast) k_loop(std::true_type{});
+        else k_loop(std::false_type{});
+    }
 
     if (ROWSUM && do_rs) {
         // a lane holds the k = 4h..4h+3 (mod 8) share of row l31 of each of its MFMA row tiles
@@ -417,6 +540,13 @@ int launch(const GemmArgs& a, int batch, int tile, bool aligned, hipStream_t str
         }
         return 0;
     }
+    if constexpr (LA == 1 && LB == 1) {
+        if (a.precision == 1) {
+            if (ts == 2) gemm_kernel<1, 1, true, 2, false, 1><<<grid, 256, 0, stream>>>(a);
+            else gemm_kernel<1, 1, true, 1, false, 1><<<grid, 256, 0, stream>>>(a);
+            return 0;
+        }
+    }
     if (ts == 2) {
         if (aligned) gemm_kernel<LA, LB, true, 2, false><<<grid, 256, 0, stream>>>(a);
         else gemm_kernel<LA, LB, false, 2, false><<<grid, 256, 0, stream>>>(a);
@@ -483,6 +613,14 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
     const long extA = ta ? (long)a.M * a.lda : (long)a.kseg * a.lda + a.M;
     const long extB = tb ? (long)a.N * a.ldb : (long)a.kseg * a.ldb + a.N;
     a.fast = aligned && a.K % BK == 0 && a.kseg % BK == 0 && extA < (1L << 31) && extB < (1L << 31);
+    a.precision = d->precision;
+    SPOT_CHECK_ARG(a.precision == 0 || a.precision == 1, "gemm: precision=%d (0 exact fp32, 1 bf16x3)", a.precision);
+    if (a.precision == 1) {
+        // whole tiles only: the bf16x3 loop has no edge handling (either tile size must divide M and N)
+        SPOT_CHECK_ARG(ta && tb && a.fast && a.splitk == 1 && a.M % 128 == 0 && a.N % 128 == 0,
+                       "gemm: bf16x3 products need k-contiguous A and B (transA = transB = 0), 16-byte aligned operands, "
+                       "K a multiple of 32, M and N multiples of 128 and no split-K (M=%d N=%d K=%d)", a.M, a.N, a.K);
+    }
     if (ta && tb) launch<1, 1>(a, d->batch, d->tile, aligned, stream);
     else if (ta && !tb) launch<1, 0>(a, d->batch, d->tile, aligned, stream);
     else if (!ta && tb) launch<0, 1>(a, d->batch, d->tile, aligned, stream);

@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
         ("relu", i32), ("mask", vp), ("ldmask", i64),
         ("residual", vp), ("ldres", i64), ("strideRes", i64),
         ("drop_p", f32), ("drop_seed", C.c_uint), ("tile", i32), ("rb_cols", i32), ("bn_gamma", vp), ("bn_beta", vp), ("bn_mean", vp), ("bn_var", vp), ("bn_eps", f32),
-        ("rowsum", vp),
+        ("rowsum", vp), ("precision", i32),
     ]
 
 

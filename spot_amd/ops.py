@@ -484,7 +484,7 @@ _GEMM_TILE = 0   # workgroup tile handed to the library: 0 = it picks per proble
 def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None, ldc=None, batch=1,
          strideA=0, strideB=0, strideC=0, kseg=0, segA=0, segB=0, splitk=1, alpha=1.0, accumulate=False,
          bias=None, rowbias=None, rb_rows=0, ldrb=0, relu=False, mask=None, ldmask=0, residual=None,
-         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0, tile=0, rowsum=None, rb_cols=0, bn=None):
+         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0, tile=0, rowsum=None, rb_cols=0, bn=None, precision=0):
     """Raw access to spot_gemm_f32; tensors are only used for their base pointers."""
     d = GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
@@ -508,10 +508,11 @@ def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None,
     d.tile = tile or _GEMM_TILE
     d.rowsum = rowsum.data_ptr() if rowsum is not None else None
     d.rb_cols = rb_cols
+    d.precision = precision
     if bn is not None:          # (gamma, beta, running_mean, running_var, eps): inference BatchNorm over the rows
         d.bn_gamma, d.bn_beta, d.bn_mean, d.bn_var = (t.data_ptr() for t in bn[:4])
         d.bn_eps = float(bn[4])
-    key = "gemm_%s%s" % ("t" if transA else "n", "n" if transB else "t")
+    key = "gemm_%s%s" % ("t" if transA else "n", "n" if transB else "t") + ("_bf16x3" if precision else "")
     if TIMER is not None and TIMER.wants(key):
         if TIMER.shapes:
             key += " M%d N%d K%d b%d sk%d" % (M, N, K, batch, splitk)
@@ -527,18 +528,31 @@ def _view2d(t):
     return t.reshape(-1, t.shape[-1])
 
 
+# Experiment switch, off in the product path: "bf16x3" takes the forward products of nn.Linear layers whose shape is made
+# of whole 128x128x32 tiles (the 256- and 1024-token layers of the fusion network) on the bf16 matrix instruction with
+# operands cut in three bf16 pieces (spot_gemm_desc.precision = 1); every other product stays exact fp32.
+LINEAR_FWD_PRECISION = "fp32"
+
+
+def _bf16x3_ok(x2, W, M, N, K):
+    return (LINEAR_FWD_PRECISION == "bf16x3" and M % 128 == 0 and N % 128 == 0 and K % 32 == 0 and
+            x2.stride(0) % 4 == 0 and W.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0 and
+            M * x2.stride(0) < 2 ** 31 and N * W.stride(0) < 2 ** 31)
+
+
 def linear_fwd(x2, W, bias=None, relu=False, residual=None, rowbias=None, out=None, drop_p=0.0, drop_seed=0):
     """y[M,N] = x2[M,K] W[N,K]^T + bias (+ rowbias[m % R], over its own columns) -> relu -> dropout -> + residual."""
     M, K = x2.shape
     N = W.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+    precision = 1 if _bf16x3_ok(x2, W, M, N, K) else 0
     gemm(x2, W, out, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=out.stride(0), bias=bias, relu=relu,
          rowbias=rowbias, rb_rows=rowbias.shape[0] if rowbias is not None else 0,
          ldrb=rowbias.stride(0) if rowbias is not None else 0,
          rb_cols=rowbias.shape[1] if rowbias is not None else 0,
          residual=residual, ldres=residual.stride(0) if residual is not None else 0, drop_p=drop_p,
-         drop_seed=drop_seed)
+         drop_seed=drop_seed, precision=precision)
     return out
 
 

@@ -1089,3 +1089,26 @@ def test_batch_channel_and_mixing_weight_reductions(ops):
     from spot_amd import lib
     lib.call("spot_groupdw_weight_grad_f32", ops._p(part_d), 300, ops._p(w_d), ops._p(dw), ops._st())
     np.testing.assert_allclose(dw.cpu().numpy(), wt.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_gemm_bf16x3_pieces_against_float64(ops):
+    """The bf16x3 experiment (spot_gemm_desc.precision = 1): operands cut into three bf16 pieces, six piece products on
+    the bf16 matrix instruction.  Its error against float64 must stay within 4x the exact-fp32 kernel's on the same
+    operands, for both workgroup tiles and with the epilogue terms; shapes it cannot take are refused, not rerouted."""
+    from spot_amd import lib
+    rng = np.random.default_rng(21)
+    for M, N, K, tile in ((256, 256, 256, 64), (1024, 768, 256, 128), (384, 128, 2048, 0)):
+        A = G((rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, 1)))).astype(np.float32))
+        W = G(rng.standard_normal((N, K)).astype(np.float32))
+        bias, res = G(rng.standard_normal(N).astype(np.float32)), G(rng.standard_normal((M, N)).astype(np.float32))
+        ref = torch.relu(A.double() @ W.double().T + bias.double()) + res.double()
+        err = {}
+        for prec in (0, 1):
+            out = torch.empty(M, N, device=DEV)
+            ops.gemm(A, W, out, M, N, K, bias=bias, relu=True, residual=res, ldres=N, tile=tile, precision=prec)
+            err[prec] = float(((out.double() - ref).abs() / (A.double().abs() @ W.double().abs().T + 1)).max())
+        assert err[1] <= 4 * err[0] + 1e-9, (M, N, K, err)
+        assert err[1] < 1e-6
+    A, W, out = G(np.ones((100, 64), np.float32)), G(np.ones((128, 64), np.float32)), torch.empty(100, 128, device=DEV)
+    with pytest.raises(RuntimeError, match="bf16x3"):
+        ops.gemm(A, W, out, 100, 128, 64, precision=1)

@@ -20,6 +20,16 @@ def G(a):
     return T(a).to(DEV)
 
 
+@pytest.fixture(params=["fp32", "bf16x3"])
+def linear_fwd(request):
+    """Both arithmetic modes of the forward nn.Linear products against the same goldens at the same tolerances: the
+    exact fp32 product path and the bf16x3 experiment (operands cut in three bf16 pieces, six piece products)."""
+    from spot_amd import ops
+    prev, ops.LINEAR_FWD_PRECISION = ops.LINEAR_FWD_PRECISION, request.param
+    yield request.param
+    ops.LINEAR_FWD_PRECISION = prev
+
+
 def build(seed, dropout=0.1):
     from spot_amd.transt import transt_resnet50
     net = transt_resnet50(Settings(device="cpu", dropout=dropout))
@@ -66,7 +76,7 @@ def test_teacher_pseudo_label_pipeline_golden(golden):
     np.testing.assert_allclose(res["aug_anno"].cpu().numpy(), g["aug_anno"], atol=0.5)
 
 
-def test_teacher_pseudo_label_pipeline_golden_at_benchmark_batch(golden):
+def test_teacher_pseudo_label_pipeline_golden_at_benchmark_batch(golden, linear_fwd):
     """The benchmark configuration's 32-clip pseudo-labelling pass against the reference's outputs: every 4th token of
     the maps, every decoded box / score / confidence, the re-projected boxes and the keep mask."""
     from spot_amd.actor import TranstSparseActor
@@ -135,7 +145,7 @@ def test_sharded_pseudo_labelling_equals_single_batch():
         assert torch.equal(torch.cat([r[k] for _, r in parts]), full_r[k]), k
 
 
-def test_student_step_golden(golden):
+def test_student_step_golden(golden, linear_fwd):
     from spot_amd.actor import TranstSparseActor
     from spot_amd.criterion import transt_loss
     from spot_amd.tensordict import TensorDict

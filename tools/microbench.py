@@ -74,6 +74,26 @@ def bench_gemm():
                                                                "sk=%d" % kw["splitk"] if "splitk" in kw else ""))
 
 
+def bench_gemm_bf16x3():
+    """Forward nn.Linear shapes: exact fp32 products against the bf16x3 experiment, time and error against float64."""
+    print("== gemm forward (A[m][k] W[n][k]): exact fp32 vs bf16x3 pieces; error = max |C - C64| / max |C64|")
+    for name, M, N, K in (("in-proj ", 40960, 768, 256), ("out-proj", 40960, 256, 256), ("ffn1    ", 40960, 2048, 256),
+                          ("ffn2    ", 40960, 256, 2048), ("in-proj ", 10240, 768, 256), ("out-proj", 10240, 256, 256),
+                          ("ffn1    ", 10240, 2048, 256), ("ffn2    ", 10240, 256, 2048)):
+        A, W, bias = r(M, K), r(N, K), r(N)
+        ref = (A[:2048].double() @ W.double().T + bias.double())
+        row = "%s M=%6d N=%5d K=%5d " % (name, M, N, K)
+        for prec in (0, 1):
+            Cc = torch.empty(M, N, device="cuda")
+            t = timeit(lambda: ops.gemm(A, W, Cc, M, N, K, bias=bias, precision=prec))
+            err = float((Cc[:2048].double() - ref).abs().max() / ref.abs().max())
+            row += " | %s %7.1f us %6.1f TF err %.2e" % ("bf16x3" if prec else "fp32  ", t * 1e6, 2.0 * M * N * K / t / 1e12, err)
+        for tile in (64, 128):
+            t = timeit(lambda: ops.gemm(A, W, Cc, M, N, K, bias=bias, precision=1, tile=tile))
+            row += " | tile %d: %7.1f us" % (tile, t * 1e6)
+        print(row)
+
+
 def bench_gemm_tiles():
     """The step's small / narrow problems under both workgroup tiles and the library's own choice."""
     print("== gemm, 64x64 vs 128x128 workgroup tile (us)")
@@ -187,5 +207,7 @@ if __name__ == "__main__":
     for name, fn in (("gemm", bench_gemm), ("gemm_tiles", bench_gemm_tiles), ("mha", bench_mha), ("xcorr", bench_xcorr), ("norm", bench_norm)):
         if what in (name, "all"):
             fn()
+    if what == "gemm_bf16x3":
+        bench_gemm_bf16x3()
     if what == "mha1":      # one shape, few launches: for counter passes under rocprofv3 --pmc
         bench_mha(((1024, 1024),), iters=4)
