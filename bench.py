@@ -107,10 +107,10 @@ KERNEL_SYMBOLS = {"gemm_nt": "gemm_kernel<1, 1, true", "gemm_nn": "gemm_kernel<1
 
 def measured_traffic(key):
     """HBM bytes per launch of the kernel class (launch-weighted over its instantiations), from the committed
-    counter passes over this same command (profiles/r1_traffic.json, written by tools/collect_traffic.sh); None if
+    counter passes over this same command (profiles/r2_traffic.json, written by tools/collect_traffic.sh); None if
     no such measurement exists."""
     symbol = KERNEL_SYMBOLS.get(key.split(" ")[0])
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r2_traffic.json")
     if symbol is None or not os.path.exists(path):
         return None, symbol
     rows = [v for k, v in json.load(open(path))["kernels"].items() if k.startswith(symbol)]
