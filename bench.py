@@ -64,9 +64,9 @@ def build_job(args, rank):
     S.aug_settings.update(gray=0.05, jitter=0.2, angle=10, lr_f_prob=0.35, ud_f_prob=0.10)
     S.strong_augmentation_tag = True
     S.attention_dtype = args.attention
-    if args.linear_fwd == "bf16x3":
+    if args.products != "f32":
         from spot_amd import ops as _ops
-        _ops.LINEAR_FWD_PRECISION = "bf16x3"
+        _ops.MATMUL_PRECISION = args.products
     ops_seed = 1000 + rank
     from spot_amd import ops as _ops
     _ops.manual_seed(ops_seed)
@@ -177,9 +177,10 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1, help="student dropout (reference config: 0.1)")
     ap.add_argument("--attention", choices=("f32", "bf16"), default="f32",
                     help="attention-core matrix products: exact fp32 (default, the headline config) or bf16")
-    ap.add_argument("--linear-fwd", choices=("f32", "bf16x3"), default="f32",
-                    help="forward products of the fusion network's nn.Linear layers: exact fp32 (default, the headline "
-                         "config) or the bf16x3 experiment (operands cut in three bf16 pieces; a separately labelled line)")
+    ap.add_argument("--products", choices=("f32", "bf16x3-linear-fwd", "bf16x3"), default="f32",
+                    help="GEMM products: exact fp32 (default, the headline config) or the bf16x3 experiment (operands cut "
+                         "in three bf16 pieces, six piece products on the bf16 matrix instruction) for the forward "
+                         "nn.Linear products only or for every GEMM launched from Python; a separately labelled line")
     ap.add_argument("--exclusive-steps", type=int, default=2,
                     help="extra untimed-for-throughput steps with the second stream off, for per-kernel durations")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -307,8 +308,10 @@ def main():
             **({"rehearsal": "all %d ranks shared GPU 0 over gloo: functional check of the multi-rank path, not a "
                              "measurement" % world} if args.rehearse_on_one_gpu else {}),
             "dtype": ("f32" if args.attention == "f32" else "f32 (bf16 attention products)") +
-                     ("" if args.linear_fwd == "f32" else " via bf16x3 (EXPERIMENT: forward nn.Linear products as six "
-                      "bf16 piece products, everything else exact fp32; not the headline configuration)"),
+                     ("" if args.products == "f32" else " via bf16x3 (EXPERIMENT: %s as six bf16 piece products, everything "
+                      "else exact fp32; not the headline configuration)"
+                      % ("forward nn.Linear products" if args.products == "bf16x3-linear-fwd" else
+                         "linear-layer, 1x1- and patch-matrix-convolution GEMMs (forward and both gradients)")),
             "data": "synthetic",
             "config": {"workload": "cfg2: %d clips x 3 frames per GPU per step; teacher pseudo-label + decode + "
                                    "filter + compaction + student fwd/bwd/AdamW on %d labelled + %d pseudo-labelled "

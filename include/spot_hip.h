@@ -210,8 +210,8 @@ typedef struct spot_gemm_desc {
                           * gradient sum_rows dY (the sum nn.Linear's backward takes separately) */
     int precision;       /* 0 = exact fp32 products (the product path).  1 = "bf16x3", an experiment: each operand is cut
                           * into three bf16 pieces (exactly) and six of the nine piece products run on the bf16 matrix
-                          * instruction with fp32 accumulation; error per product below 2^-23 |a||b|.  Only transA =
-                          * transB = 0, K % 32 == 0, M % 128 == 0, N % 128 == 0, aligned operands, no split-K;
+                          * instruction with fp32 accumulation; error per product below 2^-23 |a||b|.  Only K and every
+                          * K segment % 32 == 0, M % 128 == 0, N % 128 == 0, 16-byte aligned operands, no rowsum;
                           * anything else is refused */
 } spot_gemm_desc;
 

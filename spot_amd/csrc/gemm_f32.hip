@@ -37,7 +37,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // product exact in the fp32 accumulator); the three dropped terms are below 2^-23 |a||b|.  The pieces are made once per
 // element, when a tile goes from registers to LDS, and LDS holds three bf16 planes per operand:
 //   plane p, row r, k: byte p*PLANE + r*B3_ROW + 2k,  B3_ROW = 80 (64 bytes of k + 16 pad: 16-byte fragment reads of
-//   32 consecutive rows fall on distinct banks).  k-contiguous operands only (A[m][k], B[n][k]: the forward of nn.Linear).
+//   32 consecutive rows fall on distinct banks).  An operand stored with k as the slow index is gathered four k at a time
+//   on its way into registers, so all four layouts share the LDS image and the matrix loop.
 constexpr int B3_ROW = 80;
 __device__ __forceinline__ void split3(float4 v, uint2& hi, uint2& mid, uint2& lo) {
     const float x[4] = {v.x, v.y, v.z, v.w};
@@ -287,14 +288,33 @@ __global__ __launch_bounds__(256, PREC ? (TS == 2 ? 2 : 4) : (TS == 2 ? 3 : 6)) 
         unsigned char* const Ab = reinterpret_cast<unsigned char*>(lds);
         unsigned char* const Bb = Ab + 3 * B3_PLANE;
         float4 ra[NL], rb[NL];
+        // A thread's share of an operand tile is NL groups of four consecutive k of one row: one 16-byte load when k
+        // is the contiguous index, four 4-byte loads ld apart (lanes along the row index) when it is not.  Either
+        // way the group lands in LDS as 3 x 8 bytes at (row, k / 4).
+        int rowA[NL], kqA[NL], rowB[NL], kqB[NL];
+        unsigned oA[NL], oB[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int f = tid + 256 * i;
+            if (LA) { rowA[i] = f >> 3; kqA[i] = f & 7; oA[i] = offA[i]; }
+            else    { rowA[i] = f & (BM - 1); kqA[i] = f / BM; oA[i] = (unsigned)(4 * kqA[i] * g.lda + m0 + rowA[i]); }
+            if (LB) { rowB[i] = f >> 3; kqB[i] = f & 7; oB[i] = offB[i]; }
+            else    { rowB[i] = f & (BN - 1); kqB[i] = f / BN; oB[i] = (unsigned)(4 * kqB[i] * g.ldb + n0 + rowB[i]); }
+        }
         int left = kt1 - kt0 - 1;                      // tiles after the one the loader points at
         auto fetch_next = [&](float4 (&da)[NL], float4 (&db)[NL]) {
-            const float* Ap = A + fseg * g.segA + fkin;
-            const float* Bp = B + fseg * g.segB + fkin;
+            const float* Ap = A + fseg * g.segA + (LA ? (long)fkin : (long)fkin * g.lda);
+            const float* Bp = B + fseg * g.segB + (LB ? (long)fkin : (long)fkin * g.ldb);
 #pragma unroll
-            for (int i = 0; i < NL; ++i) da[i] = *reinterpret_cast<const float4*>(Ap + offA[i]);
+            for (int i = 0; i < NL; ++i) {
+                if (LA) da[i] = *reinterpret_cast<const float4*>(Ap + oA[i]);
+                else da[i] = make_float4(Ap[oA[i]], (Ap + g.lda)[oA[i]], (Ap + 2 * g.lda)[oA[i]], (Ap + 3 * g.lda)[oA[i]]);
+            }
 #pragma unroll
-            for (int i = 0; i < NL; ++i) db[i] = *reinterpret_cast<const float4*>(Bp + offB[i]);
+            for (int i = 0; i < NL; ++i) {
+                if (LB) db[i] = *reinterpret_cast<const float4*>(Bp + oB[i]);
+                else db[i] = make_float4(Bp[oB[i]], (Bp + g.ldb)[oB[i]], (Bp + 2 * g.ldb)[oB[i]], (Bp + 3 * g.ldb)[oB[i]]);
+            }
             const int adv = left > 0, nk = fkin + BK, wrap = nk >= g.kseg;
             left -= adv;
             fkin = adv ? (wrap ? 0 : nk) : fkin;
@@ -303,16 +323,16 @@ __global__ __launch_bounds__(256, PREC ? (TS == 2 ? 2 : 4) : (TS == 2 ? 3 : 6)) 
         auto stage = [&](const float4 (&da)[NL], const float4 (&db)[NL]) {
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
-                const int f = tid + 256 * i, at = (f >> 3) * B3_ROW + ((f & 7) << 3);
                 uint2 p0, p1, p2;
+                const int atA = rowA[i] * B3_ROW + (kqA[i] << 3), atB = rowB[i] * B3_ROW + (kqB[i] << 3);
                 split3(da[i], p0, p1, p2);
-                *reinterpret_cast<uint2*>(Ab + at) = p0;
-                *reinterpret_cast<uint2*>(Ab + B3_PLANE + at) = p1;
-                *reinterpret_cast<uint2*>(Ab + 2 * B3_PLANE + at) = p2;
+                *reinterpret_cast<uint2*>(Ab + atA) = p0;
+                *reinterpret_cast<uint2*>(Ab + B3_PLANE + atA) = p1;
+                *reinterpret_cast<uint2*>(Ab + 2 * B3_PLANE + atA) = p2;
                 split3(db[i], p0, p1, p2);
-                *reinterpret_cast<uint2*>(Bb + at) = p0;
-                *reinterpret_cast<uint2*>(Bb + B3_PLANE + at) = p1;
-                *reinterpret_cast<uint2*>(Bb + 2 * B3_PLANE + at) = p2;
+                *reinterpret_cast<uint2*>(Bb + atB) = p0;
+                *reinterpret_cast<uint2*>(Bb + B3_PLANE + atB) = p1;
+                *reinterpret_cast<uint2*>(Bb + 2 * B3_PLANE + atB) = p2;
             }
         };
         auto body = [&](float4 (&xa)[NL], float4 (&xb)[NL]) {
@@ -540,12 +560,10 @@ int launch(const GemmArgs& a, int batch, int tile, bool aligned, hipStream_t str
         }
         return 0;
     }
-    if constexpr (LA == 1 && LB == 1) {
-        if (a.precision == 1) {
-            if (ts == 2) gemm_kernel<1, 1, true, 2, false, 1><<<grid, 256, 0, stream>>>(a);
-            else gemm_kernel<1, 1, true, 1, false, 1><<<grid, 256, 0, stream>>>(a);
-            return 0;
-        }
+    if (a.precision == 1) {
+        if (ts == 2) gemm_kernel<LA, LB, true, 2, false, 1><<<grid, 256, 0, stream>>>(a);
+        else gemm_kernel<LA, LB, true, 1, false, 1><<<grid, 256, 0, stream>>>(a);
+        return 0;
     }
     if (ts == 2) {
         if (aligned) gemm_kernel<LA, LB, true, 2, false><<<grid, 256, 0, stream>>>(a);
@@ -617,9 +635,9 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
     SPOT_CHECK_ARG(a.precision == 0 || a.precision == 1, "gemm: precision=%d (0 exact fp32, 1 bf16x3)", a.precision);
     if (a.precision == 1) {
         // whole tiles only: the bf16x3 loop has no edge handling (either tile size must divide M and N)
-        SPOT_CHECK_ARG(ta && tb && a.fast && a.splitk == 1 && a.M % 128 == 0 && a.N % 128 == 0,
-                       "gemm: bf16x3 products need k-contiguous A and B (transA = transB = 0), 16-byte aligned operands, "
-                       "K a multiple of 32, M and N multiples of 128 and no split-K (M=%d N=%d K=%d)", a.M, a.N, a.K);
+        SPOT_CHECK_ARG(a.fast && a.M % 128 == 0 && a.N % 128 == 0 && !a.rowsum,
+                       "gemm: bf16x3 products need 16-byte aligned operands, K (and every K segment) a multiple of 32, "
+                       "M and N multiples of 128 and no row sums (M=%d N=%d K=%d)", a.M, a.N, a.K);
     }
     if (ta && tb) launch<1, 1>(a, d->batch, d->tile, aligned, stream);
     else if (ta && !tb) launch<1, 0>(a, d->batch, d->tile, aligned, stream);

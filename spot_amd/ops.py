@@ -481,10 +481,30 @@ def _join_after_backward():
 _GEMM_TILE = 0   # workgroup tile handed to the library: 0 = it picks per problem; 64 / 128 force one (same results)
 
 
+# Experiment switch, off in the product path ("fp32": every product exact).  "bf16x3-linear-fwd" takes the forward
+# products of nn.Linear layers, "bf16x3" every GEMM launched from here (linear layers forward, input and weight
+# gradients, 1x1 and patch-matrix convolutions, input_proj; not the Winograd products, which the library launches
+# itself) on the bf16 matrix instruction with operands cut in three bf16 pieces (spot_gemm_desc.precision = 1), wherever
+# the problem is made of whole 128 x 128 x 32 tiles of aligned operands; every other launch stays exact fp32.
+MATMUL_PRECISION = "fp32"
+
+
+def _bf16x3_ok(A, B, M, N, K, transA, transB, d, rowsum):
+    """The library's conditions for precision = 1 (it refuses anything else)."""
+    if M % 128 or N % 128 or K % 32 or rowsum is not None or (d.kseg and d.kseg % 32):
+        return False
+    if A.data_ptr() % 16 or B.data_ptr() % 16 or d.lda % 4 or d.ldb % 4 or d.strideA % 4 or d.strideB % 4 or d.segA % 4 or d.segB % 4:
+        return False
+    kseg = d.kseg or K
+    ext_a = kseg * d.lda + M if transA else M * d.lda
+    ext_b = kseg * d.ldb + N if transB else N * d.ldb
+    return ext_a < 2 ** 31 and ext_b < 2 ** 31
+
+
 def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None, ldc=None, batch=1,
          strideA=0, strideB=0, strideC=0, kseg=0, segA=0, segB=0, splitk=1, alpha=1.0, accumulate=False,
          bias=None, rowbias=None, rb_rows=0, ldrb=0, relu=False, mask=None, ldmask=0, residual=None,
-         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0, tile=0, rowsum=None, rb_cols=0, bn=None, precision=0):
+         ldres=0, strideRes=0, drop_p=0.0, drop_seed=0, tile=0, rowsum=None, rb_cols=0, bn=None, precision=None):
     """Raw access to spot_gemm_f32; tensors are only used for their base pointers."""
     d = GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
@@ -508,6 +528,12 @@ def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None,
     d.tile = tile or _GEMM_TILE
     d.rowsum = rowsum.data_ptr() if rowsum is not None else None
     d.rb_cols = rb_cols
+    # precision: 0 / 1 as given (the library refuses a 1 it cannot do); "try": bf16x3 if the problem qualifies;
+    # None: by MATMUL_PRECISION
+    if precision is None:
+        precision = "try" if MATMUL_PRECISION == "bf16x3" else 0
+    if precision == "try":
+        precision = 1 if _bf16x3_ok(A, B, M, N, K, transA, transB, d, rowsum) else 0
     d.precision = precision
     if bn is not None:          # (gamma, beta, running_mean, running_var, eps): inference BatchNorm over the rows
         d.bn_gamma, d.bn_beta, d.bn_mean, d.bn_var = (t.data_ptr() for t in bn[:4])
@@ -528,25 +554,13 @@ def _view2d(t):
     return t.reshape(-1, t.shape[-1])
 
 
-# Experiment switch, off in the product path: "bf16x3" takes the forward products of nn.Linear layers whose shape is made
-# of whole 128x128x32 tiles (the 256- and 1024-token layers of the fusion network) on the bf16 matrix instruction with
-# operands cut in three bf16 pieces (spot_gemm_desc.precision = 1); every other product stays exact fp32.
-LINEAR_FWD_PRECISION = "fp32"
-
-
-def _bf16x3_ok(x2, W, M, N, K):
-    return (LINEAR_FWD_PRECISION == "bf16x3" and M % 128 == 0 and N % 128 == 0 and K % 32 == 0 and
-            x2.stride(0) % 4 == 0 and W.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0 and
-            M * x2.stride(0) < 2 ** 31 and N * W.stride(0) < 2 ** 31)
-
-
 def linear_fwd(x2, W, bias=None, relu=False, residual=None, rowbias=None, out=None, drop_p=0.0, drop_seed=0):
     """y[M,N] = x2[M,K] W[N,K]^T + bias (+ rowbias[m % R], over its own columns) -> relu -> dropout -> + residual."""
     M, K = x2.shape
     N = W.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x2.device)
-    precision = 1 if _bf16x3_ok(x2, W, M, N, K) else 0
+    precision = "try" if MATMUL_PRECISION == "bf16x3-linear-fwd" else None
     gemm(x2, W, out, M, N, K, lda=x2.stride(0), ldb=W.stride(0), ldc=out.stride(0), bias=bias, relu=relu,
          rowbias=rowbias, rb_rows=rowbias.shape[0] if rowbias is not None else 0,
          ldrb=rowbias.stride(0) if rowbias is not None else 0,

@@ -1094,21 +1094,39 @@ def test_batch_channel_and_mixing_weight_reductions(ops):
 def test_gemm_bf16x3_pieces_against_float64(ops):
     """The bf16x3 experiment (spot_gemm_desc.precision = 1): operands cut into three bf16 pieces, six piece products on
     the bf16 matrix instruction.  Its error against float64 must stay within 4x the exact-fp32 kernel's on the same
-    operands, for both workgroup tiles and with the epilogue terms; shapes it cannot take are refused, not rerouted."""
-    from spot_amd import lib
+    operands, for all four operand layouts, both workgroup tiles, split-K, batches and the epilogue terms; shapes it
+    cannot take are refused by the library, and passed to the exact kernel when the mode is only a preference."""
     rng = np.random.default_rng(21)
-    for M, N, K, tile in ((256, 256, 256, 64), (1024, 768, 256, 128), (384, 128, 2048, 0)):
-        A = G((rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, 1)))).astype(np.float32))
-        W = G(rng.standard_normal((N, K)).astype(np.float32))
-        bias, res = G(rng.standard_normal(N).astype(np.float32)), G(rng.standard_normal((M, N)).astype(np.float32))
-        ref = torch.relu(A.double() @ W.double().T + bias.double()) + res.double()
+    for ta, tb, M, N, K, tile, sk, batch in ((0, 0, 256, 256, 256, 64, 1, 1), (0, 0, 1024, 768, 256, 128, 1, 1),
+                                              (0, 0, 384, 128, 2048, 0, 1, 1), (0, 1, 512, 256, 768, 0, 1, 1),
+                                              (0, 1, 256, 384, 128, 128, 1, 1), (1, 1, 256, 128, 4096, 0, 4, 1),
+                                              (1, 1, 128, 256, 1024, 64, 1, 1), (1, 0, 256, 256, 512, 0, 1, 3),
+                                              (0, 1, 128, 1024, 64, 0, 1, 2)):
+        scale = np.exp(rng.uniform(-6, 6, (M, 1)))
+        a64 = rng.standard_normal((M, K)) * scale
+        A = G((a64.T if ta else a64).astype(np.float32).copy())
+        b64 = rng.standard_normal((batch, K, N))
+        Bm = G((b64 if tb else b64.transpose(0, 2, 1)).astype(np.float32).copy())
+        Ad = (A.T if ta else A).double()
+        Bd = (Bm if tb else Bm.transpose(1, 2)).double()                  # [batch, K, N]
+        bias, res = G(rng.standard_normal(N).astype(np.float32)), G(rng.standard_normal((batch, M, N)).astype(np.float32))
+        plain = Ad @ Bd + bias.double()
+        ref = plain if sk > 1 else torch.relu(plain) + res.double()
         err = {}
         for prec in (0, 1):
-            out = torch.empty(M, N, device=DEV)
-            ops.gemm(A, W, out, M, N, K, bias=bias, relu=True, residual=res, ldres=N, tile=tile, precision=prec)
-            err[prec] = float(((out.double() - ref).abs() / (A.double().abs() @ W.double().abs().T + 1)).max())
-        assert err[1] <= 4 * err[0] + 1e-9, (M, N, K, err)
-        assert err[1] < 1e-6
+            out = torch.zeros(batch, M, N, device=DEV)
+            kw = dict(transA=bool(ta), transB=bool(tb), bias=bias, tile=tile, precision=prec, batch=batch,
+                      strideB=K * N if batch > 1 else 0, strideC=M * N if batch > 1 else 0)
+            if sk > 1:
+                kw.update(splitk=sk, accumulate=True)
+            else:
+                kw.update(relu=True, residual=res, ldres=N, strideRes=M * N if batch > 1 else 0)
+            ops.gemm(A, Bm, out, M, N, K, **kw)
+            err[prec] = float(((out.double() - ref).abs() / (Ad.abs() @ Bd.abs() + 1)).max())
+        assert err[1] <= 4 * err[0] + 1e-9, (ta, tb, M, N, K, err)
+        assert err[1] < 1e-6, (ta, tb, M, N, K, err)
     A, W, out = G(np.ones((100, 64), np.float32)), G(np.ones((128, 64), np.float32)), torch.empty(100, 128, device=DEV)
     with pytest.raises(RuntimeError, match="bf16x3"):
         ops.gemm(A, W, out, 100, 128, 64, precision=1)
+    ops.gemm(A, W, out, 100, 128, 64, precision="try")                     # a preference: the exact kernel takes it
+    assert float(out.min()) == 64.0 and float(out.max()) == 64.0
