@@ -153,40 +153,31 @@ class Ocean_Tracker(object):
             else:
                 self._target_dev.copy_(tgt)
             res = self._run_frame(net, x_crops, p).cpu().numpy()                               # the frame's one D2H read
-        _, _, pred_x1, pred_y1, pred_x2, pred_y2, penalty, score = res
-        score = np.float32(score)
-        pred_xs, pred_ys = (pred_x1 + pred_x2) / 2, (pred_y1 + pred_y2) / 2
-        pred_w, pred_h = pred_x2 - pred_x1, pred_y2 - pred_y1
-        diff_xs, diff_ys = pred_xs - p.instance_size // 2, pred_ys - p.instance_size // 2
-        diff_xs, diff_ys, pred_w, pred_h = diff_xs / scale_z, diff_ys / scale_z, pred_w / scale_z, pred_h / scale_z
-        target_sz = target_sz / scale_z
-        lr = penalty * score * p.lr
-        res_xs, res_ys = target_pos[0] + diff_xs, target_pos[1] + diff_ys
-        res_w = pred_w * lr + (1 - lr) * target_sz[0]
-        res_h = pred_h * lr + (1 - lr) * target_sz[1]
-        target_pos = np.array([res_xs, res_ys])
-        target_sz = target_sz * (1 - lr) + lr * np.array([res_w, res_h])
-        return target_pos, target_sz, score
+        corners, penalty, score = res[2:6], res[6], np.float32(res[7])          # (x1, y1, x2, y2) of the winning cell
+        # crop pixels -> frame pixels: offset of the box centre from the crop centre and the box extent, both / scale_z
+        centre, extent = (corners[:2] + corners[2:]) / 2, corners[2:] - corners[:2]
+        shift, extent = (centre - p.instance_size // 2) / scale_z, extent / scale_z
+        previous = target_sz / scale_z
+        lr = penalty * score * p.lr                                             # size learning rate (ocean_tracker.py:118)
+        blended = extent * lr + (1 - lr) * previous
+        return np.asarray(target_pos, dtype=np.float64) + shift, previous * (1 - lr) + lr * blended, score
 
     def track(self, image, info: dict = None) -> dict:
         state = self.state
         p, net, avg_chans, window = state["p"], state["net"], state["avg_chans"], state["window"]
         target_pos, target_sz = state["target_pos"], state["target_sz"]
-        hc_z = target_sz[1] + p.context_amount * sum(target_sz)
-        wc_z = target_sz[0] + p.context_amount * sum(target_sz)
-        s_z = np.sqrt(wc_z * hc_z)
+        context = p.context_amount * sum(target_sz)
+        s_z = np.sqrt((target_sz[0] + context) * (target_sz[1] + context))     # side of the template-scale window
         scale_z = p.exemplar_size / s_z
-        d_search = (p.instance_size - p.exemplar_size) / 2
-        pad = d_search / scale_z
-        s_x = s_z + 2 * pad
+        s_x = s_z + 2 * ((p.instance_size - p.exemplar_size) / 2 / scale_z)     # widened to the search crop
         x_crop = self.get_subwindow_tracking(image, target_pos, p.instance_size, self.python2round(s_x), avg_chans)
         self._frame = None
         target_pos, target_sz, cls_score = self.update(net, self._normalize(x_crop), target_pos, target_sz * scale_z,
                                                        window, scale_z, p)
-        target_pos[0] = max(0, min(state["im_w"], target_pos[0]))
-        target_pos[1] = max(0, min(state["im_h"], target_pos[1]))
-        target_sz[0] = max(10, min(state["im_w"], target_sz[0]))
-        target_sz[1] = max(10, min(state["im_h"], target_sz[1]))
+        frame = (state["im_w"], state["im_h"])
+        for axis in (0, 1):                                    # centre inside the frame, sides between 10 px and the frame's
+            target_pos[axis] = max(0, min(frame[axis], target_pos[axis]))
+            target_sz[axis] = max(10, min(frame[axis], target_sz[axis]))
         state["target_pos"], state["target_sz"] = target_pos, target_sz
         self.state = state
         return {"target_bbox": [target_pos[0] - target_sz[0] / 2, target_pos[1] - target_sz[1] / 2, target_sz[0], target_sz[1]],

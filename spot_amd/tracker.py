@@ -85,12 +85,18 @@ class TransT_Tracker(object):
         self._graph = None
         self._eager_frames = 0
 
+    @staticmethod
+    def _crop_side(size, factor):
+        """Side of the square crop around a target of the given (w, h): each side grown by (factor - 1) times the mean
+        side, geometric mean of the two, rounded up (transt_tracker.py:121-123,143-145)."""
+        margin = (factor - 1) * ((size[0] + size[1]) * 0.5)
+        return math.ceil(math.sqrt((size[0] + margin) * (size[1] + margin)))
+
     def _bbox_clip(self, cx, cy, width, height, boundary):
-        cx = max(0, min(cx, boundary[1]))
-        cy = max(0, min(cy, boundary[0]))
-        width = max(10, min(width, boundary[1]))
-        height = max(10, min(height, boundary[0]))
-        return cx, cy, width, height
+        """Centre kept inside the frame, sides between 10 px and the frame's (transt_tracker.py:34-39)."""
+        frame_h, frame_w = boundary[0], boundary[1]
+        keep = lambda v, lo, hi: max(lo, min(v, hi))
+        return keep(cx, 0, frame_w), keep(cy, 0, frame_h), keep(width, 10, frame_w), keep(height, 10, frame_h)
 
     def get_subwindow(self, im, pos, model_sz, original_sz, avg_chans):
         """Square crop of side original_sz around pos, padded with the channel average and resized to model_sz
@@ -136,9 +142,7 @@ class TransT_Tracker(object):
         bbox = info["init_bbox"]
         self.center_pos = np.array([bbox[0] + bbox[2] / 2, bbox[1] + bbox[3] / 2])
         self.size = np.array([bbox[2], bbox[3]])
-        w_z = self.size[0] + (2 - 1) * ((self.size[0] + self.size[1]) * 0.5)
-        h_z = self.size[1] + (2 - 1) * ((self.size[0] + self.size[1]) * 0.5)
-        s_z = math.ceil(math.sqrt(w_z * h_z))
+        s_z = self._crop_side(self.size, 2)
         self.channel_average = (image.float().mean(dim=(0, 1)).cpu().numpy() if torch.is_tensor(image)
                                 else np.mean(image, axis=(0, 1)))
         z_crop = self.get_subwindow(image, self.center_pos, self.exemplar_size, s_z, self.channel_average)
@@ -200,19 +204,15 @@ class TransT_Tracker(object):
         return self._buf_static
 
     def track(self, image, info: dict = None) -> dict:
-        w_x = self.size[0] + (4 - 1) * ((self.size[0] + self.size[1]) * 0.5)
-        h_x = self.size[1] + (4 - 1) * ((self.size[0] + self.size[1]) * 0.5)
-        s_x = math.ceil(math.sqrt(w_x * h_x))
+        s_x = self._crop_side(self.size, 4)
         x_crop = self.get_subwindow(image, self.center_pos, self.instance_size, round(s_x), self.channel_average)
         self._frame = None
         res = self._run_frame(x_crop).cpu().numpy()            # the frame's one device->host read
-        bx, by, bw, bh = res[2:6]
         pscore = res[6:]
-        bbox = np.array([bx, by, bw, bh], dtype=np.float32) * s_x
-        cx = bbox[0] + self.center_pos[0] - s_x / 2
-        cy = bbox[1] + self.center_pos[1] - s_x / 2
-        cx, cy, width, height = self._bbox_clip(cx, cy, bbox[2], bbox[3], image.shape[:2])
-        self.center_pos = np.array([cx, cy])
-        self.size = np.array([width, height])
-        out_bbox = [cx - width / 2, cy - height / 2, width, height]
-        return {"target_bbox": out_bbox, "best_score": pscore}
+        # the winning token's box, crop-relative in [0, 1] -> frame pixels (float32 product as in the reference)
+        box = res[2:6].astype(np.float32) * s_x
+        half = s_x / 2                                         # crop centre = the previous target centre
+        cx, cy, width, height = self._bbox_clip(box[0] + self.center_pos[0] - half, box[1] + self.center_pos[1] - half,
+                                                box[2], box[3], image.shape[:2])
+        self.center_pos, self.size = np.array([cx, cy]), np.array([width, height])
+        return {"target_bbox": [cx - width / 2, cy - height / 2, width, height], "best_score": pscore}
