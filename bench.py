@@ -254,9 +254,12 @@ def main():
         fusion.TWO_STREAMS = False
         step(args.warmup + args.steps, lookahead=False)          # settle into the serial schedule
         exclusive = ops.TIMER = ops.KernelTimer(only=only)
+        torch.cuda.synchronize()
+        tx = time.perf_counter()
         for i in range(args.exclusive_steps):
             step(args.warmup + args.steps + 1 + i, lookahead=False)
         torch.cuda.synchronize()
+        exclusive_ms = (time.perf_counter() - tx) / args.exclusive_steps * 1e3
         ops.TIMER = None
         fusion.TWO_STREAMS = two
     per_rank_ms = [el / args.steps * 1e3]
@@ -294,6 +297,9 @@ def main():
                     roofline["second_stream_off"] = {
                         "achieved": round(xa, 2), "frac": round(xa / PEAK_F32_MFMA_TFLOPS, 4),
                         "avg_us": round(x["ms"] * 1e3 / x["launches"], 2), "launches": x["launches"],
+                        "ms_per_step_serial_schedule": round(exclusive_ms, 3),
+                        "kernel_ms_per_step": {k: round(v["ms"] / args.exclusive_steps, 3)
+                                               for k, v in exclusive.summary().items()},
                         "note": "same kernels in %d extra steps with the template stream serialised behind the "
                                 "search stream and no look-ahead teacher pass: a launch then has the chip to itself"
                                 % args.exclusive_steps}

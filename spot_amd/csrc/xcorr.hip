@@ -1313,7 +1313,11 @@ __global__ __launch_bounds__(256, PART == 0 ? 3 : 4) void groupdw_bwd_row_kernel
                 // the items past the first 256 (a few rows of the last strip) go to a different wave for every branch
                 const int item = base + (base == 0 ? tid : ((tid + 192 - 64 * i) & 255));
                 const bool active = item < nitems;
-                const int strip = item / hx, row = item - strip * hx, j0 = strip * 8;
+                // strips fastest: a wave's stores then cover whole consecutive rows of dx (1 KB per store instruction in
+                // 8 lines instead of 64 pieces in 64 lines); the price is a 2-way bank conflict on 2 of 16 lanes of the
+                // LDS reads
+                const int nst = (wx + 7) >> 3;
+                const int row = item / nst, strip = item - row * nst, j0 = strip * 8;
                 float r[8];
                 if (active) {          // the taps: broadcast 8-byte LDS reads, every lane gets the same pairs
                     if (i == 0) {
