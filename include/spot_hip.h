@@ -198,7 +198,11 @@ typedef struct spot_gemm_desc {
     long ldres, strideRes;
     float drop_p;        /* dropout after relu and before mask/residual: v = keep ? v/(1-p) : 0; 0 = off */
     unsigned drop_seed;  /* mask = f(drop_seed, global row z*M + m, column n): see spot_dropout_f32 */
-    int tile;            /* workgroup tile: 0 = chosen from the problem shape, 64 = 64x64, 128 = 128x128 (same results) */
+    int tile;            /* workgroup tile: 0 = 64x64 or 128x128, chosen from the problem shape (bit-identical results, so
+                          * the arithmetic never depends on the batch size); 64 / 128 force one.  32 = a 32x32 tile whose
+                          * four waves split every 128-wide k step, for launches too small to fill the chip (one clip: the
+                          * online trackers): deterministic, but another summation order; needs M, N % 32 == 0, K and every
+                          * K segment % 128 == 0, aligned operands, no split-K / rowsum, else refused */
     int rb_cols;         /* rowbias covers columns n < rb_cols only (0 = all N columns) */
     const float* bn_gamma;  /* [M] each, or bn_gamma = null: inference-mode BatchNorm over the rows, applied after the */
     const float* bn_beta;   /* bias terms: v = v*a + (beta[m] - mean[m]*a), a = gamma[m] / sqrt(var[m] + bn_eps)      */

@@ -155,8 +155,10 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int g, in
 // ROWSUM: the workgroups of the first tile column also add the row sums of opA(A) into g.rowsum (the bias
 // gradient of a linear layer when A is the transposed output gradient: its tiles pass through here anyway).
 // PREC: 0 = exact fp32 products, 1 = bf16x3 (interior tiles of k-contiguous operands only; the host checks)
-template <int LA, int LB, bool ALIGNED, int TS, bool ROWSUM, int PREC = 0>   // LA: 1 = MK (k-contiguous), 0 = KM;  LB: 1 = NK, 0 = KN
-__global__ __launch_bounds__(256, PREC ? (TS == 2 ? 2 : 4) : (TS == 2 ? 3 : 6)) void gemm_kernel(GemmArgs g) {
+// DEEP: exact fp32 with the loads of four k tiles in flight per workgroup, for grids of at most a few workgroups per CU
+//       (one clip: the online trackers), where nothing else hides the memory latency of a k step
+template <int LA, int LB, bool ALIGNED, int TS, bool ROWSUM, int PREC = 0, bool DEEP = false>   // LA: 1 = MK (k-contiguous), 0 = KM;  LB: 1 = NK, 0 = KN
+__global__ __launch_bounds__(256, DEEP ? 2 : (PREC ? (TS == 2 ? 2 : 4) : (TS == 2 ? 3 : 6))) void gemm_kernel(GemmArgs g) {
     using T = Tile<TS>;
     constexpr int BM = T::BM, BN = T::BN, NL = T::NL, MPAD = T::MPAD, TILE_F = T::TILE_F, CPAD = T::CPAD;
     constexpr int RSH = T::RSH, RMASK = (1 << RSH) - 1, WT = 32 * TS;   // WT: rows (cols) of a wave's sub-tile
@@ -378,17 +380,100 @@ __global__ __launch_bounds__(256, PREC ? (TS == 2 ? 2 : 4) : (TS == 2 ? 3 : 6)) 
             }
             __syncthreads();                           // the staged tile is visible
         };
-        fetch_next(sa, sb);
-        stage(sa, sb);
-        fetch_next(sa, sb);
-        fetch_next(ra, rb);
+        if (kt0 < kt1) {        // an empty k range of a split-K launch starts past the end of the operands: no loads
+            fetch_next(sa, sb);
+            stage(sa, sb);
+            fetch_next(sa, sb);
+            fetch_next(ra, rb);
+        }
         __syncthreads();
         for (int kt = kt0; kt < kt1; kt += 2) {
             body(sa, sb);
             if (kt + 1 < kt1) body(ra, rb);
         }
     };
-    if constexpr (PREC == 1) {
+    // Deep-prefetch loop.  With one workgroup per CU the 16 matrix instructions of a k step (0.5 us) cannot cover a
+    // global load (1-2 us), and the loop above keeps only the next tile in flight: a k step then costs a memory
+    // latency.  Here four tiles are in flight in four register sets; the barriers order LDS traffic only (a full
+    // __syncthreads would wait for every outstanding load and undo the prefetch).
+    auto k_loop_deep = [&]() {
+        static_assert(!DEEP || TS == 1, "the deep-prefetch loop is written for the 64x64 tile (two 16-byte loads per thread and operand)");
+        constexpr int D = 4;
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        struct Set { f32x4 a0, a1, b0, b1; };           // native vectors (the float4 class is copied by memcpy, which pins it in scratch)
+        Set s0, s1, s2, s3;
+        auto lds_barrier = [] {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        };
+        // LDS slots of this thread's two vectors per operand (as store_tile places them)
+        const int f0 = tid, f1 = tid + 256;
+        float* const la0 = As + (LA ? (f0 >> 3) * KPAD + ((f0 & 7) << 2) : (f0 >> RSH) * MPAD + ((f0 & RMASK) << 2));
+        float* const la1 = As + (LA ? (f1 >> 3) * KPAD + ((f1 & 7) << 2) : (f1 >> RSH) * MPAD + ((f1 & RMASK) << 2));
+        float* const lb0 = Bs + (LB ? (f0 >> 3) * KPAD + ((f0 & 7) << 2) : (f0 >> RSH) * MPAD + ((f0 & RMASK) << 2));
+        float* const lb1 = Bs + (LB ? (f1 >> 3) * KPAD + ((f1 & 7) << 2) : (f1 >> RSH) * MPAD + ((f1 & RMASK) << 2));
+        int left = kt1 - kt0 - 1;                      // tiles after the one the loader points at
+        // (written as macros over the named sets: handed to a lambda by reference the sets end up in scratch memory)
+        // the loader always loads: past the last k tile it stays on it (a duplicate that is never staged)
+#define SPOT_DEEP_FETCH(RS)                                                                        \
+        {                                                                                         \
+            const float* Ab = A + fseg * g.segA + (LA ? (long)fkin : (long)fkin * g.lda);         \
+            const float* Bb = B + fseg * g.segB + (LB ? (long)fkin : (long)fkin * g.ldb);         \
+            RS.a0 = *reinterpret_cast<const f32x4*>(Ab + offA[0]);                                 \
+            RS.a1 = *reinterpret_cast<const f32x4*>(Ab + offA[1]);                                \
+            RS.b0 = *reinterpret_cast<const f32x4*>(Bb + offB[0]);                                \
+            RS.b1 = *reinterpret_cast<const f32x4*>(Bb + offB[1]);                                \
+            const int adv = left > 0, nk = fkin + BK, wrap = nk >= g.kseg;                        \
+            left -= adv;                                                                          \
+            fkin = adv ? (wrap ? 0 : nk) : fkin;                                                  \
+            fseg += adv & wrap;                                                                   \
+        }
+#define SPOT_DEEP_STEP(RS)                                                                         \
+        {                                                                                         \
+            *reinterpret_cast<f32x4*>(la0) = RS.a0;                                               \
+            *reinterpret_cast<f32x4*>(la1) = RS.a1;                                               \
+            *reinterpret_cast<f32x4*>(lb0) = RS.b0;                                               \
+            *reinterpret_cast<f32x4*>(lb1) = RS.b1;                                               \
+            lds_barrier();                                                                        \
+            SPOT_DEEP_FETCH(RS)                                                                    \
+            _Pragma("unroll") for (int gk = 0; gk < BK / 8; ++gk) {                               \
+                const float4 a = read_frag<LA, MPAD>(As, wm * WT + l31, gk, h);                   \
+                const float4 b = read_frag<LB, MPAD>(Bs, wn * WT + l31, gk, h);                   \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);   \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[0][0], 0, 0, 0);   \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[0][0], 0, 0, 0);   \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[0][0], 0, 0, 0);   \
+            }                                                                                     \
+            lds_barrier();                                                                        \
+        }
+        // (a split-K launch can hand a workgroup an empty k range, which starts past the end of the operands: nothing
+        //  may be loaded then)
+        if (kt0 < kt1) {
+        SPOT_DEEP_FETCH(s0)
+        SPOT_DEEP_FETCH(s1)
+        SPOT_DEEP_FETCH(s2)
+        SPOT_DEEP_FETCH(s3)
+        // whole rounds of four steps without a branch inside (the wait counts for "this set's loads, not the twelve
+        // younger ones" need every path to have issued the same number of loads), then the 0-3 steps that are left
+        int kt = kt0;
+        for (; kt + D <= kt1; kt += D) {
+            SPOT_DEEP_STEP(s0)
+            SPOT_DEEP_STEP(s1)
+            SPOT_DEEP_STEP(s2)
+            SPOT_DEEP_STEP(s3)
+        }
+        if (kt < kt1) SPOT_DEEP_STEP(s0)
+        if (kt + 1 < kt1) SPOT_DEEP_STEP(s1)
+        if (kt + 2 < kt1) SPOT_DEEP_STEP(s2)
+        }
+#undef SPOT_DEEP_STEP
+#undef SPOT_DEEP_FETCH
+        __syncthreads();
+    };
+    if constexpr (DEEP) {
+        k_loop_deep();
+    } else if constexpr (PREC == 1) {
         k_loop_bf16x3();
     } else {
         if (fast) k_loop(std::true_type{});
@@ -529,6 +614,134 @@ __global__ __launch_bounds__(256, PREC ? (TS == 2 ? 2 : 4) : (TS == 2 ? 3 : 6)) 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Small grids (one clip: the online trackers' 256- and 1024-token layers).  With 16 to 64 tiles of 64x64 most CUs idle and
+// a launch lasts as long as one wave's chain of K/2 dependent matrix instructions (52 us at M = 1024, N = 256, K = 2048).
+// Here a workgroup owns a 32x32 output tile and its four waves split every 128-wide k step between them: four times as
+// many workgroups, a chain a quarter as long.  The four partial tiles are summed through LDS in a fixed order (no
+// atomics: the same bits on every run), then the usual epilogue runs on one float4 per thread.
+// Whole tiles of aligned operands only (M, N multiples of 32, K and every K segment multiples of 128); the host checks.
+// ---------------------------------------------------------------------------
+constexpr int KS_TM = 32, KS_K = 128, KS_KP = KS_K + 4, KS_MP = KS_TM + 4, KS_TILE_F = KS_K * KS_MP;   // 4608 >= 32 * 132
+
+template <int LA, int LB>
+__global__ __launch_bounds__(256, 2) void gemm_ks4_kernel(GemmArgs g) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float lds[2 * KS_TILE_F];
+    float* const As = lds;
+    float* const Bs = lds + KS_TILE_F;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int ntn = g.N / KS_TM;
+    const int m0 = (blockIdx.x / ntn) * KS_TM, n0 = (blockIdx.x % ntn) * KS_TM;
+    const int zb = blockIdx.z;
+    const float* A = g.A + zb * g.strideA;
+    const float* B = g.B + zb * g.strideB;
+
+    // a thread's four 16-byte pieces of each operand tile: global element offsets and LDS slots
+    unsigned offA[4], offB[4];
+    int ldsA[4], ldsB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        if (LA) { offA[i] = (unsigned)((m0 + (f >> 5)) * g.lda + ((f & 31) << 2)); ldsA[i] = (f >> 5) * KS_KP + ((f & 31) << 2); }
+        else    { offA[i] = (unsigned)((f >> 3) * g.lda + m0 + ((f & 7) << 2));    ldsA[i] = (f >> 3) * KS_MP + ((f & 7) << 2); }
+        if (LB) { offB[i] = (unsigned)((n0 + (f >> 5)) * g.ldb + ((f & 31) << 2)); ldsB[i] = (f >> 5) * KS_KP + ((f & 31) << 2); }
+        else    { offB[i] = (unsigned)((f >> 3) * g.ldb + n0 + ((f & 7) << 2));    ldsB[i] = (f >> 3) * KS_MP + ((f & 7) << 2); }
+    }
+    f32x4 ra[4], rb[4];
+    int fseg = 0, fkin = 0;
+    auto fetch = [&]() {
+        const float* Ab = A + fseg * g.segA + (LA ? (long)fkin : (long)fkin * g.lda);
+        const float* Bb = B + fseg * g.segB + (LB ? (long)fkin : (long)fkin * g.ldb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(Ab + offA[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Bb + offB[i]);
+        fkin += KS_K;
+        if (fkin >= g.kseg) {
+            fkin = 0;
+            ++fseg;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int nst = g.K / KS_K;
+    fetch();
+    for (int st = 0; st < nst; ++st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(As + ldsA[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Bs + ldsB[i]) = rb[i];
+        __syncthreads();
+        if (st + 1 < nst) fetch();
+        const int kw = 32 * wave;                     // this wave's quarter of the k step
+#pragma unroll
+        for (int gk = 0; gk < 4; ++gk) {
+            const int k = kw + gk * 8 + 4 * h;        // lane half h takes k .. k+3 of the 8-wide group, on both operands
+            float4 a, b;
+            if (LA) a = *reinterpret_cast<const float4*>(As + l31 * KS_KP + k);
+            else { const float* p = As + k * KS_MP + l31; a = make_float4(p[0], p[KS_MP], p[2 * KS_MP], p[3 * KS_MP]); }
+            if (LB) b = *reinterpret_cast<const float4*>(Bs + l31 * KS_KP + k);
+            else { const float* p = Bs + k * KS_MP + l31; b = make_float4(p[0], p[KS_MP], p[2 * KS_MP], p[3 * KS_MP]); }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // the four partial tiles: accumulator element e sits at row (e&3) + 8 (e>>2) + 4h, column lane & 31
+    float* red = lds + wave * (KS_TM * KS_MP);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[((e & 3) + 8 * (e >> 2) + 4 * h) * KS_MP + l31] = acc[e];
+    __syncthreads();
+    const int row = tid >> 3, c4 = (tid & 7) << 2, m = m0 + row, n = n0 + c4;
+    float4 v = *reinterpret_cast<const float4*>(lds + row * KS_MP + c4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const float4 p = *reinterpret_cast<const float4*>(lds + w * (KS_TM * KS_MP) + row * KS_MP + c4);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    // epilogue, in the order of gemm_kernel's
+    v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
+    if (g.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(g.bias + n);
+        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+    }
+    if (g.rowbias && n < g.rb_cols) {
+        const float4 r4 = *reinterpret_cast<const float4*>(g.rowbias + (long)(m % g.rb_rows) * g.ldrb + n);
+        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+    }
+    if (g.bn_gamma) {
+        const float sc = g.bn_gamma[m] / sqrtf(g.bn_var[m] + g.bn_eps), sh = g.bn_beta[m] - g.bn_mean[m] * sc;
+        v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+    }
+    if (g.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (g.drop_thr) {
+        const unsigned rk = spot_row_key(g.drop_seed, (unsigned)(zb * g.M + m));
+        v.x = spot_keep(rk, n, g.drop_thr) ? v.x * g.drop_scale : 0.f;
+        v.y = spot_keep(rk, n + 1, g.drop_thr) ? v.y * g.drop_scale : 0.f;
+        v.z = spot_keep(rk, n + 2, g.drop_thr) ? v.z * g.drop_scale : 0.f;
+        v.w = spot_keep(rk, n + 3, g.drop_thr) ? v.w * g.drop_scale : 0.f;
+    }
+    if (g.mask) {
+        const float4 k4 = *reinterpret_cast<const float4*>(g.mask + (long)m * g.ldmask + n);
+        v.x = k4.x > 0.f ? v.x : 0.f; v.y = k4.y > 0.f ? v.y : 0.f; v.z = k4.z > 0.f ? v.z : 0.f; v.w = k4.w > 0.f ? v.w : 0.f;
+    }
+    if (g.residual) {
+        const float4 r4 = *reinterpret_cast<const float4*>(g.residual + zb * g.strideRes + (long)m * g.ldres + n);
+        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+    }
+    if (g.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    float* cp = g.C + zb * g.strideC + (long)m * g.ldc + n;
+    if (g.accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(cp);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *reinterpret_cast<float4*>(cp) = v;
+}
+
 // Workgroup tile for a problem.  Measured on MI355X the two tiles reach the same rate per FLOP (the 64x64 one
 // keeps six workgroups per CU in flight against three), so the choice is about quantisation: MFMA work is handed
 // out in workgroups, the last round of a grid leaves CUs idle, and a 64x64 workgroup is a quarter of the work.
@@ -536,7 +749,7 @@ __global__ __launch_bounds__(256, PREC ? (TS == 2 ? 2 : 4) : (TS == 2 ? 3 : 6)) 
 // does not matter.
 int pick_tile(const GemmArgs& a, int batch, int forced) {
     if (forced == 128) return 2;
-    if (forced == 64) return 1;
+    if (forced == 64 || forced == 32) return 1;
     auto wgs = [&](int b) { return (long)((a.M + b - 1) / b) * ((a.N + b - 1) / b) * batch * a.splitk; };
     const long CUS = 256;
     const long w128 = wgs(128);
@@ -563,6 +776,19 @@ int launch(const GemmArgs& a, int batch, int tile, bool aligned, hipStream_t str
     if (a.precision == 1) {
         if (ts == 2) gemm_kernel<LA, LB, true, 2, false, 1><<<grid, 256, 0, stream>>>(a);
         else gemm_kernel<LA, LB, true, 1, false, 1><<<grid, 256, 0, stream>>>(a);
+        return 0;
+    }
+    // tile = 32 (asked for by the online trackers for one clip's layers): 32x32 tiles with the k step split over the waves
+    if (tile == 32) {
+        dim3 gks((a.M / KS_TM) * (a.N / KS_TM), 1, batch);
+        gemm_ks4_kernel<LA, LB><<<gks, 256, 0, stream>>>(a);
+        return 0;
+    }
+    // a grid of at most two workgroups per CU whose tiles are all interior ones: the deep-prefetch loop (same
+    // products in the same order, so the same bits)
+    const int nkt_split = ((a.K + BK - 1) / BK + a.splitk - 1) / a.splitk;
+    if (ts == 1 && aligned && a.fast && a.M % 64 == 0 && a.N % 64 == 0 && (long)grid.x * grid.z <= 512 && nkt_split >= 3) {
+        gemm_kernel<LA, LB, true, 1, false, 0, true><<<grid, 256, 0, stream>>>(a);
         return 0;
     }
     if (ts == 2) {
@@ -606,7 +832,7 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
     SPOT_CHECK_ARG(!a.rowsum || (d->transA && d->transB && d->batch == 1),
                    "gemm: rowsum is for the weight-gradient layout (transA = transB = 1, batch = 1)");
     SPOT_CHECK_ARG(a.kseg % BK == 0 || a.kseg >= a.K, "gemm: kseg=%d must be a multiple of %d", a.kseg, BK);
-    SPOT_CHECK_ARG(d->tile == 0 || d->tile == 64 || d->tile == 128, "gemm: tile=%d (0, 64 or 128)", d->tile);
+    SPOT_CHECK_ARG(d->tile == 0 || d->tile == 32 || d->tile == 64 || d->tile == 128, "gemm: tile=%d (0, 32, 64 or 128)", d->tile);
     SPOT_CHECK_ARG(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p=%f outside [0,1)", d->drop_p);
     a.drop_thr = spot_drop_threshold(d->drop_p);
     a.drop_seed = d->drop_seed;
@@ -631,6 +857,12 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
     const long extA = ta ? (long)a.M * a.lda : (long)a.kseg * a.lda + a.M;
     const long extB = tb ? (long)a.N * a.ldb : (long)a.kseg * a.ldb + a.N;
     a.fast = aligned && a.K % BK == 0 && a.kseg % BK == 0 && extA < (1L << 31) && extB < (1L << 31);
+    if (d->tile == 32) {
+        SPOT_CHECK_ARG(aligned && a.fast && a.cvec && a.splitk == 1 && !a.rowsum && d->precision == 0 && a.M % KS_TM == 0 &&
+                           a.N % KS_TM == 0 && a.K % KS_K == 0 && (a.kseg % KS_K == 0 || a.kseg >= a.K),
+                       "gemm: tile=32 needs 16-byte aligned operands and epilogue terms, M and N multiples of 32, K (and "
+                       "every K segment) a multiple of 128, no split-K, no row sums (M=%d N=%d K=%d)", a.M, a.N, a.K);
+    }
     a.precision = d->precision;
     SPOT_CHECK_ARG(a.precision == 0 || a.precision == 1, "gemm: precision=%d (0 exact fp32, 1 bf16x3)", a.precision);
     if (a.precision == 1) {

@@ -501,6 +501,18 @@ def _bf16x3_ok(A, B, M, N, K, transA, transB, d, rowsum):
     return ext_a < 2 ** 31 and ext_b < 2 ** 31
 
 
+def _small_grid_ok(A, B, Cout, M, N, K, d, rowsum):
+    """Launches of at most 128 tiles of 64x64 (half the CUs) that the library's tile = 32 kernel accepts."""
+    if ((M + 63) // 64) * ((N + 63) // 64) * d.batch > 128 or M % 32 or N % 32 or K % 128 or (d.kseg and d.kseg % 128):
+        return False
+    if rowsum is not None or d.splitk > 1 or d.precision:
+        return False
+    ptrs = [A.data_ptr(), B.data_ptr(), Cout.data_ptr(), d.bias or 0, d.rowbias or 0, d.mask or 0, d.residual or 0]
+    lds = [d.lda, d.ldb, d.ldc, d.strideA, d.strideB, d.strideC, d.segA, d.segB, d.ldrb, d.ldmask, d.ldres, d.strideRes,
+           d.rb_cols]
+    return all(p % 16 == 0 for p in ptrs) and all(v % 4 == 0 for v in lds)
+
+
 def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None, ldc=None, batch=1,
          strideA=0, strideB=0, strideC=0, kseg=0, segA=0, segB=0, splitk=1, alpha=1.0, accumulate=False,
          bias=None, rowbias=None, rb_rows=0, ldrb=0, relu=False, mask=None, ldmask=0, residual=None,
@@ -535,6 +547,8 @@ def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None,
     if precision == "try":
         precision = 1 if _bf16x3_ok(A, B, M, N, K, transA, transB, d, rowsum) else 0
     d.precision = precision
+    if not d.tile and frozen_weights._active and not torch.is_grad_enabled() and _small_grid_ok(A, B, Cout, M, N, K, d, rowsum):
+        d.tile = 32         # one clip (the online trackers): k-splitting 32x32 tile, see spot_gemm_desc.tile
     if bn is not None:          # (gamma, beta, running_mean, running_var, eps): inference BatchNorm over the rows
         d.bn_gamma, d.bn_beta, d.bn_mean, d.bn_var = (t.data_ptr() for t in bn[:4])
         d.bn_eps = float(bn[4])

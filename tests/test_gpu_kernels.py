@@ -1130,3 +1130,47 @@ def test_gemm_bf16x3_pieces_against_float64(ops):
         ops.gemm(A, W, out, 100, 128, 64, precision=1)
     ops.gemm(A, W, out, 100, 128, 64, precision="try")                     # a preference: the exact kernel takes it
     assert float(out.min()) == 64.0 and float(out.max()) == 64.0
+
+
+def test_gemm_small_grid_kernels_against_float64(ops):
+    """tile = 32 (the 32x32-tile kernel whose four waves split the k step, asked for by the online trackers) and, for
+    the larger shapes of the list, the deep-prefetch loop small grids take on their own: all four operand layouts,
+    batches, every epilogue term and accumulation against float64; two runs give the same bits (the partial tiles are
+    summed in a fixed order); a shape the kernel cannot take is refused."""
+    rng = np.random.default_rng(33)
+    for ta, tb, M, N, K, batch in ((0, 0, 1024, 256, 256, 1), (0, 0, 256, 256, 2048, 1), (0, 1, 256, 1024, 1024, 1),
+                                   (1, 1, 512, 256, 384, 2), (1, 0, 1024, 256, 1024, 1), (0, 1, 64, 4096, 256, 1),
+                                   (0, 0, 1024, 1024, 256, 1), (0, 1, 2048, 512, 256, 1)):
+        a64 = rng.standard_normal((M, K))
+        A = G((a64.T if ta else a64).astype(np.float32).copy())
+        b64 = rng.standard_normal((batch, K, N))
+        Bm = G((b64 if tb else b64.transpose(0, 2, 1)).astype(np.float32).copy())
+        Ad = (A.T if ta else A).double()
+        Bd = (Bm if tb else Bm.transpose(1, 2)).double()
+        bias = G(rng.standard_normal(N).astype(np.float32))
+        rowb = G(rng.standard_normal((128, N)).astype(np.float32))
+        res = G(rng.standard_normal((batch, M, N)).astype(np.float32))
+        mask = G(rng.standard_normal((M, N)).astype(np.float32))
+        start = G(rng.standard_normal((batch, M, N)).astype(np.float32))
+        idx = torch.arange(M, device=DEV) % 128
+        ref = torch.relu(0.5 * (Ad @ Bd) + bias.double() + rowb.double()[idx])
+        ref = torch.where(mask.double() > 0, ref, torch.zeros((), dtype=torch.float64, device=DEV)) + res.double() + start.double()
+        outs = []
+        for _ in range(2):
+            out = start.clone()
+            ops.gemm(A, Bm, out, M, N, K, transA=bool(ta), transB=bool(tb), alpha=0.5, bias=bias, rowbias=rowb, rb_rows=128,
+                     ldrb=N, relu=True, mask=mask, ldmask=N, residual=res, ldres=N, strideRes=M * N if batch > 1 else 0,
+                     batch=batch, strideB=K * N if batch > 1 else 0, strideC=M * N if batch > 1 else 0, accumulate=True,
+                     tile=32 if M * N * batch <= 128 * 4096 else 0)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+        err = float((outs[0].double() - ref).abs().max())
+        assert err < 2e-5 * math.sqrt(K), (ta, tb, M, N, K, batch, err)
+    # split-K whose last range is empty (9 k tiles over 4 ranges of 3): that workgroup must not touch the operands
+    A, W = G(rng.standard_normal((128, 288)).astype(np.float32)), G(rng.standard_normal((128, 288)).astype(np.float32))
+    out = torch.zeros(128, 128, device=DEV)
+    ops.gemm(A, W, out, 128, 128, 288, splitk=4, accumulate=True)
+    np.testing.assert_allclose(out.cpu().double().numpy(), (A.double() @ W.double().T).cpu().numpy(), rtol=1e-5, atol=2e-4)
+    A, W, out = G(np.ones((64, 96), np.float32)), G(np.ones((64, 96), np.float32)), torch.empty(64, 64, device=DEV)
+    with pytest.raises(RuntimeError, match="tile=32"):
+        ops.gemm(A, W, out, 64, 64, 96, tile=32)
