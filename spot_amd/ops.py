@@ -501,9 +501,12 @@ def _bf16x3_ok(A, B, M, N, K, transA, transB, d, rowsum):
     return ext_a < 2 ** 31 and ext_b < 2 ** 31
 
 
+_KS_MAX_TILES = 128         # 256 and 512 measure the same on the tracker (569 / 583 / 568 frames/s)
+
+
 def _small_grid_ok(A, B, Cout, M, N, K, d, rowsum):
     """Launches of at most 128 tiles of 64x64 (half the CUs) that the library's tile = 32 kernel accepts."""
-    if ((M + 63) // 64) * ((N + 63) // 64) * d.batch > 128 or M % 32 or N % 32 or K % 128 or (d.kseg and d.kseg % 128):
+    if ((M + 63) // 64) * ((N + 63) // 64) * d.batch > _KS_MAX_TILES or M % 32 or N % 32 or K % 128 or (d.kseg and d.kseg % 128):
         return False
     if rowsum is not None or d.splitk > 1 or d.precision:
         return False
