@@ -24,6 +24,7 @@
 #include "common.h"
 #include "../../include/spot_hip.h"
 #include <type_traits>
+#include <cstdint>
 
 namespace {
 
@@ -152,6 +153,150 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int g, in
     return make_float4(p[0], p[MPAD], p[2 * MPAD], p[3 * MPAD]);
 }
 
+// What follows the k loop, shared by the workgroup-tile kernels: the bias gradient's row sums, then the epilogue.
+// `lds` is the kernel's whole LDS allocation (free after the k loop; at least 64 x CPAD floats), `zb` / `zs` the batch
+// and split-K indices of this workgroup, (m0, n0) its tile origin.
+template <int TS, bool ROWSUM>
+__device__ __forceinline__ void finish_tile(const GemmArgs& g, f32x16 (&acc)[TS][TS], float (&rs)[TS], bool do_rs, float* lds,
+                                            int m0, int n0, int zb, int zs, int tid) {
+    using T = Tile<TS>;
+    constexpr int BN = T::BN, CPAD = T::CPAD, RSH = T::RSH, RMASK = (1 << RSH) - 1, WT = 32 * TS;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+    if (ROWSUM && do_rs) {
+        // a lane holds the k = 4h..4h+3 (mod 8) share of row l31 of each of its MFMA row tiles
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+            const float v = rs[t] + __shfl_xor(rs[t], 32);
+            const int m = m0 + wm * WT + t * 32 + l31;
+            if (h == 0 && m < g.M) atomicAdd(g.rowsum + m, v);
+        }
+    }
+
+    // epilogue.  Per-lane dword stores of the accumulator layout (32 floats per row segment) are
+    // store-issue bound, so the tile is transposed through LDS (free after the k loop) and leaves
+    // the chip as 16-byte stores of whole 512-byte rows; bias / row-bias / mask / residual are
+    // read the same way.  Accumulator element e of tile (t,u): row (e&3)+8*(e>>2)+4h, col lane&31.
+    float* Cs = lds;
+    float* C = g.C + zb * g.strideC;
+    const bool first = zs == 0;                      // additive terms enter once under split-K
+    const float* res = (g.residual && first) ? g.residual + zb * g.strideRes : nullptr;
+    const float* rowbias = first ? g.rowbias : nullptr;
+    const float* bias = first ? g.bias : nullptr;
+    constexpr int CSH = RSH;                          // log2(float4 per staged C row)
+    const int c4 = (tid & RMASK) << 2;
+    const int n = n0 + c4;
+    const bool full = g.cvec && n + 3 < g.N;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && g.splitk == 1 && n < g.N) {
+        if (full) bv = *reinterpret_cast<const float4*>(bias + n);
+        else {
+            bv.x = bias[n];
+            if (n + 1 < g.N) bv.y = bias[n + 1];
+            if (n + 2 < g.N) bv.z = bias[n + 2];
+            if (n + 3 < g.N) bv.w = bias[n + 3];
+        }
+    }
+    // the staging tile holds 64 rows at a time: for the 128-row tile, rows of the wm = 0 waves first, then wm = 1
+    for (int half = 0; half < TS; ++half) {
+        if (half) __syncthreads();
+        if (TS == 1 || wm == half) {
+            const int rbase = TS == 1 ? wm * 32 : 0;
+#pragma unroll
+            for (int t = 0; t < TS; ++t)
+#pragma unroll
+                for (int u = 0; u < TS; ++u)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        Cs[(rbase + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CPAD + wn * WT + u * 32 + l31] = acc[t][u][e];
+        }
+        __syncthreads();
+        const int mh = m0 + half * 64;
+        if (g.splitk > 1) {
+            // split-K partial sums: one dword per lane, 64 consecutive floats per wave-instruction
+            // (the shape float atomics run at full rate in)
+            const int col = tid & (BN - 1), nn = n0 + col;
+            if (nn < g.N) {
+                const float b1 = bias ? bias[nn] : 0.f;
+                for (int i = 0; i < 64 / (256 / BN); ++i) {
+                    const int row = i * (256 / BN) + tid / BN, m = mh + row;
+                    if (m >= g.M) break;
+                    float x = Cs[row * CPAD + col] * g.alpha + b1;
+                    if (rowbias && nn < g.rb_cols) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + nn];
+                    if (res) x += res[(long)m * g.ldres + nn];
+                    atomicAdd(C + (long)m * g.ldc + nn, x);
+                }
+            }
+            continue;
+        }
+        if (n >= g.N) continue;
+#pragma unroll 4
+        for (int i = 0; i < (64 >> (8 - CSH)); ++i) {
+            const int row = (i << (8 - CSH)) + (tid >> CSH);
+            const int m = mh + row;
+            if (m >= g.M) break;
+            float4 v = *reinterpret_cast<const float4*>(Cs + row * CPAD + c4);
+            v.x = v.x * g.alpha + bv.x; v.y = v.y * g.alpha + bv.y; v.z = v.z * g.alpha + bv.z; v.w = v.w * g.alpha + bv.w;
+            float* cp = C + (long)m * g.ldc + n;
+            if (full) {
+                if (rowbias && n < g.rb_cols) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(rowbias + (long)(m % g.rb_rows) * g.ldrb + n);
+                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                }
+                if (g.bn_gamma) {
+                    const float sc = g.bn_gamma[m] / sqrtf(g.bn_var[m] + g.bn_eps), sh = g.bn_beta[m] - g.bn_mean[m] * sc;
+                    v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+                }
+                if (g.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (g.drop_thr) {
+                    const unsigned rk = spot_row_key(g.drop_seed, (unsigned)(zb * g.M + m));
+                    v.x = spot_keep(rk, n, g.drop_thr) ? v.x * g.drop_scale : 0.f;
+                    v.y = spot_keep(rk, n + 1, g.drop_thr) ? v.y * g.drop_scale : 0.f;
+                    v.z = spot_keep(rk, n + 2, g.drop_thr) ? v.z * g.drop_scale : 0.f;
+                    v.w = spot_keep(rk, n + 3, g.drop_thr) ? v.w * g.drop_scale : 0.f;
+                }
+                if (g.mask) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(g.mask + (long)m * g.ldmask + n);
+                    v.x = k4.x > 0.f ? v.x : 0.f; v.y = k4.y > 0.f ? v.y : 0.f;
+                    v.z = k4.z > 0.f ? v.z : 0.f; v.w = k4.w > 0.f ? v.w : 0.f;
+                }
+                if (res) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(res + (long)m * g.ldres + n);
+                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                }
+                if (g.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (g.accumulate) {
+                    float4 o = *reinterpret_cast<float4*>(cp);
+                    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                    *reinterpret_cast<float4*>(cp) = o;
+                } else {
+                    *reinterpret_cast<float4*>(cp) = v;
+                }
+            } else {
+                float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j >= g.N) break;
+                    float x = vv[j];
+                    if (rowbias && n + j < g.rb_cols) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + n + j];
+                    if (g.bn_gamma) {
+                        const float sc = g.bn_gamma[m] / sqrtf(g.bn_var[m] + g.bn_eps);
+                        x = fmaf(x, sc, g.bn_beta[m] - g.bn_mean[m] * sc);
+                    }
+                    if (g.relu == 1) x = fmaxf(x, 0.f);
+                    if (g.drop_thr)
+                        x = spot_keep(spot_row_key(g.drop_seed, (unsigned)(zb * g.M + m)), n + j, g.drop_thr) ? x * g.drop_scale : 0.f;
+                    if (g.mask) x = g.mask[(long)m * g.ldmask + n + j] > 0.f ? x : 0.f;
+                    if (res) x += res[(long)m * g.ldres + n + j];
+                    if (g.relu == 2) x = fmaxf(x, 0.f);
+                    if (g.accumulate) cp[j] += x;
+                    else cp[j] = x;
+                }
+            }
+        }
+    }
+}
+
 // ROWSUM: the workgroups of the first tile column also add the row sums of opA(A) into g.rowsum (the bias
 // gradient of a linear layer when A is the transposed output gradient: its tiles pass through here anyway).
 // PREC: 0 = exact fp32 products, 1 = bf16x3 (interior tiles of k-contiguous operands only; the host checks)
@@ -160,7 +305,7 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int row, int g, in
 template <int LA, int LB, bool ALIGNED, int TS, bool ROWSUM, int PREC = 0, bool DEEP = false>   // LA: 1 = MK (k-contiguous), 0 = KM;  LB: 1 = NK, 0 = KN
 __global__ __launch_bounds__(256, DEEP ? 2 : (PREC ? (TS == 2 ? 2 : 4) : (TS == 2 ? 3 : 6))) void gemm_kernel(GemmArgs g) {
     using T = Tile<TS>;
-    constexpr int BM = T::BM, BN = T::BN, NL = T::NL, MPAD = T::MPAD, TILE_F = T::TILE_F, CPAD = T::CPAD;
+    constexpr int BM = T::BM, BN = T::BN, NL = T::NL, MPAD = T::MPAD, TILE_F = T::TILE_F;
     constexpr int RSH = T::RSH, RMASK = (1 << RSH) - 1, WT = 32 * TS;   // WT: rows (cols) of a wave's sub-tile
     constexpr int B3_PLANE = BM * B3_ROW;                               // bytes per bf16 plane of one operand
     __shared__ __attribute__((aligned(16))) float lds[PREC ? 6 * B3_PLANE / 4 : 2 * TILE_F];
@@ -480,138 +625,172 @@ __global__ __launch_bounds__(256, DEEP ? 2 : (PREC ? (TS == 2 ? 2 : 4) : (TS == 
         else k_loop(std::false_type{});
     }
 
-    if (ROWSUM && do_rs) {
-        // a lane holds the k = 4h..4h+3 (mod 8) share of row l31 of each of its MFMA row tiles
+    finish_tile<TS, ROWSUM>(g, acc, rs, do_rs, lds, m0, n0, zb, zs, tid);
+}
+
+// ---------------------------------------------------------------------------
+// Ring kernel: the same workgroup tiles, products and summation order as gemm_kernel (so the same bits), for problems
+// made of whole tiles of aligned operands.  Operand tiles go global -> LDS directly (global_load_lds_dwordx4: no
+// register staging, no LDS store instructions) into a ring of two stages with ONE barrier per k tile: the loads of
+// tile k+1 are issued right behind the barrier that retires tile k and land while tile k is multiplied.
+//   LDS image of a k-contiguous operand: the tile's 128-byte k rows, unpadded (a wave instruction writes 8 whole rows in
+//     lane order), 16-byte chunk c of row r stored at chunk position c ^ ((r >> 1) & 7): the 16-byte fragment reads of
+//     16 consecutive rows then cover all 64 banks once.
+//   LDS image of an m/n-contiguous operand: 32 k rows of BM floats, unpadded, chunk c of k row kk at position
+//     c ^ (((kk >> 2) & 1) << 3): lane half h = 1 (k + 4) reads the other 128-byte half of the bank row than h = 0.
+//   Either swizzle is applied on the per-lane SOURCE address (the LDS destination of a direct load is lane-linear).
+// The direct loads are written as asm: the compiler's wait-count insertion would otherwise drain every outstanding
+// direct load before each LDS read; the k loop therefore holds no compiler-visible vector-memory load at all and
+// waits with its own s_waitcnt.
+// ---------------------------------------------------------------------------
+template <int GA> __device__ __forceinline__ void direct_load_pieces(const float* base, const unsigned (&voff)[GA], unsigned lds_addr);
+// GA consecutive 1 KiB pieces: lane's 16 bytes from base + voff[j] bytes, piece j at LDS byte address lds_addr + 1024 j
+template <> __device__ __forceinline__ void direct_load_pieces<2>(const float* base, const unsigned (&voff)[2], unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "s"(base), "s"(lds_addr) : "memory", "scc");
+}
+template <> __device__ __forceinline__ void direct_load_pieces<4>(const float* base, const unsigned (&voff)[4], unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(base), "s"(lds_addr) : "memory", "scc");
+}
+
+template <int LA, int LB, int TS, bool ROWSUM>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs g) {
+    using T = Tile<TS>;
+    constexpr int BM = T::BM, BN = T::BN, WT = 32 * TS;
+    constexpr int A_F = BM * BK, STAGE_F = (BM + BN) * BK;        // floats per operand tile / per stage
+    constexpr int GA = BM / 32;                                    // 1 KiB pieces per wave per operand tile
+    static_assert(2 * STAGE_F >= 64 * T::CPAD, "the epilogue's staging tile must fit in the ring");
+    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE_F];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+    const int ntn = g.N / BN, ntm = g.M / BM, nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, x = bid & 7, loc = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+    const int zb = blockIdx.z / g.splitk, zs = blockIdx.z % g.splitk;
+    const int nkt = g.K / BK;
+    const int per = (nkt + g.splitk - 1) / g.splitk;
+    const int kt0 = zs * per, kt1 = min(nkt, kt0 + per);
+
+    // tile origins at k = 0 (scalar), and the lane's byte offset inside a tile for each of the wave's pieces
+    const float* Ao = g.A + zb * g.strideA + (LA ? (long)m0 * g.lda : (long)m0);
+    const float* Bo = g.B + zb * g.strideB + (LB ? (long)n0 * g.ldb : (long)n0);
+    unsigned voA[GA], voB[GA];
 #pragma unroll
-        for (int t = 0; t < TS; ++t) {
-            const float v = rs[t] + __shfl_xor(rs[t], 32);
-            const int m = m0 + wm * WT + t * 32 + l31;
-            if (h == 0 && m < g.M) atomicAdd(g.rowsum + m, v);
+    for (int j = 0; j < GA; ++j) {
+        const int i = wave * GA + j;                               // piece index inside the operand tile
+        if (LA) {
+            const int row = 8 * i + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            voA[j] = 4u * (unsigned)(row * g.lda + 4 * c);
+        } else {
+            constexpr int CH = BM / 4;                             // 16-byte chunks per k row
+            const int kk = i * (256 / BM) + lane / CH, c = (lane % CH) ^ (((kk >> 2) & 1) << 3);
+            voA[j] = 4u * (unsigned)(kk * g.lda + 4 * c);
         }
+        if (LB) {
+            const int row = 8 * i + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            voB[j] = 4u * (unsigned)(row * g.ldb + 4 * c);
+        } else {
+            constexpr int CH = BN / 4;
+            const int kk = i * (256 / BN) + lane / CH, c = (lane % CH) ^ (((kk >> 2) & 1) << 3);
+            voB[j] = 4u * (unsigned)(kk * g.ldb + 4 * c);
+        }
+    }
+    // fragment read offsets (floats inside an operand tile).  k-contiguous: one per 8-wide k group (16-byte read of row
+    // l31 of the wave's sub-tile 0; sub-tile t is 32 rows further).  m/n-contiguous: one per sub-tile (k row 4h, the
+    // lane's column swizzled); k group and element are whole k rows further.
+    int fak[4], fbk[4], fam[TS], fbm[TS];
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) {
+        fak[gk] = (wm * WT + l31) * BK + (((2 * gk + h) ^ ((l31 >> 1) & 7)) << 2);
+        fbk[gk] = (wn * WT + l31) * BK + (((2 * gk + h) ^ ((l31 >> 1) & 7)) << 2);
+    }
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+        fam[t] = 4 * h * BM + ((wm * WT + t * 32 + l31) ^ (h << 5));
+        fbm[t] = 4 * h * BN + ((wn * WT + t * 32 + l31) ^ (h << 5));
     }
 
-    // epilogue.  Per-lane dword stores of the accumulator layout (32 floats per row segment) are
-    // store-issue bound, so the tile is transposed through LDS (free after the k loop) and leaves
-    // the chip as 16-byte stores of whole 512-byte rows; bias / row-bias / mask / residual are
-    // read the same way.  Accumulator element e of tile (t,u): row (e&3)+8*(e>>2)+4h, col lane&31.
-    float* Cs = lds;
-    float* C = g.C + zb * g.strideC;
-    const bool first = zs == 0;                      // additive terms enter once under split-K
-    const float* res = (g.residual && first) ? g.residual + zb * g.strideRes : nullptr;
-    const float* rowbias = first ? g.rowbias : nullptr;
-    const float* bias = first ? g.bias : nullptr;
-    constexpr int CSH = RSH;                          // log2(float4 per staged C row)
-    const int c4 = (tid & RMASK) << 2;
-    const int n = n0 + c4;
-    const bool full = g.cvec && n + 3 < g.N;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias && g.splitk == 1 && n < g.N) {
-        if (full) bv = *reinterpret_cast<const float4*>(bias + n);
-        else {
-            bv.x = bias[n];
-            if (n + 1 < g.N) bv.y = bias[n + 1];
-            if (n + 2 < g.N) bv.z = bias[n + 2];
-            if (n + 3 < g.N) bv.w = bias[n + 3];
+    f32x16 acc[TS][TS];
+#pragma unroll
+    for (int t = 0; t < TS; ++t)
+#pragma unroll
+        for (int u = 0; u < TS; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+    float rs[TS];
+#pragma unroll
+    for (int t = 0; t < TS; ++t) rs[t] = 0.f;
+    const bool do_rs = ROWSUM && n0 == 0 && wn == 0;
+
+    const unsigned lds0 = (unsigned)(uintptr_t)lds + (unsigned)__builtin_amdgcn_readfirstlane(wave) * (GA * 1024u);
+    int fseg = (kt0 * BK) / g.kseg, fkin = kt0 * BK - fseg * g.kseg;     // position of the next tile to fetch
+    auto issue = [&](int slot) {
+        const float* Ap = Ao + fseg * g.segA + (LA ? (long)fkin : (long)fkin * g.lda);
+        const float* Bp = Bo + fseg * g.segB + (LB ? (long)fkin : (long)fkin * g.ldb);
+        const unsigned dst = lds0 + (unsigned)slot * (STAGE_F * 4u);
+        direct_load_pieces<GA>(Ap, voA, dst);
+        direct_load_pieces<GA>(Bp, voB, dst + A_F * 4u);
+        fkin += BK;
+        if (fkin >= g.kseg) {
+            fkin = 0;
+            ++fseg;
         }
-    }
-    // the staging tile holds 64 rows at a time: for the 128-row tile, rows of the wm = 0 waves first, then wm = 1
-    for (int half = 0; half < TS; ++half) {
-        if (half) __syncthreads();
-        if (TS == 1 || wm == half) {
-            const int rbase = TS == 1 ? wm * 32 : 0;
+    };
+    if (kt0 < kt1) issue(0);       // an empty k range of a split-K launch starts past the end of the operands: no loads
+    int slot = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile kt have landed
+        __builtin_amdgcn_s_barrier();                              // everyone's have; everyone is done reading the other slot
+        if (kt + 1 < kt1) issue(slot ^ 1);
+        const float* As = lds + slot * STAGE_F;
+        const float* Bs = As + A_F;
+#pragma unroll
+        for (int gk = 0; gk < BK / 8; ++gk) {
+            float4 a[TS], b[TS];
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                if (LA) a[t] = *reinterpret_cast<const float4*>(As + fak[gk] + t * 32 * BK);
+                else { const float* q = As + fam[t] + gk * 8 * BM; a[t] = make_float4(q[0], q[BM], q[2 * BM], q[3 * BM]); }
+            }
+#pragma unroll
+            for (int u = 0; u < TS; ++u) {
+                if (LB) b[u] = *reinterpret_cast<const float4*>(Bs + fbk[gk] + u * 32 * BK);
+                else { const float* q = Bs + fbm[u] + gk * 8 * BN; b[u] = make_float4(q[0], q[BN], q[2 * BN], q[3 * BN]); }
+            }
+            if (ROWSUM && do_rs) {
+#pragma unroll
+                for (int t = 0; t < TS; ++t) rs[t] += (a[t].x + a[t].y) + (a[t].z + a[t].w);
+            }
 #pragma unroll
             for (int t = 0; t < TS; ++t)
 #pragma unroll
-                for (int u = 0; u < TS; ++u)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        Cs[(rbase + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CPAD + wn * WT + u * 32 + l31] = acc[t][u][e];
+                for (int u = 0; u < TS; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
+                }
         }
-        __syncthreads();
-        const int mh = m0 + half * 64;
-        if (g.splitk > 1) {
-            // split-K partial sums: one dword per lane, 64 consecutive floats per wave-instruction
-            // (the shape float atomics run at full rate in)
-            const int col = tid & (BN - 1), nn = n0 + col;
-            if (nn < g.N) {
-                const float b1 = bias ? bias[nn] : 0.f;
-                for (int i = 0; i < 64 / (256 / BN); ++i) {
-                    const int row = i * (256 / BN) + tid / BN, m = mh + row;
-                    if (m >= g.M) break;
-                    float x = Cs[row * CPAD + col] * g.alpha + b1;
-                    if (rowbias && nn < g.rb_cols) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + nn];
-                    if (res) x += res[(long)m * g.ldres + nn];
-                    atomicAdd(C + (long)m * g.ldc + nn, x);
-                }
-            }
-            continue;
-        }
-        if (n >= g.N) continue;
-#pragma unroll 4
-        for (int i = 0; i < (64 >> (8 - CSH)); ++i) {
-            const int row = (i << (8 - CSH)) + (tid >> CSH);
-            const int m = mh + row;
-            if (m >= g.M) break;
-            float4 v = *reinterpret_cast<const float4*>(Cs + row * CPAD + c4);
-            v.x = v.x * g.alpha + bv.x; v.y = v.y * g.alpha + bv.y; v.z = v.z * g.alpha + bv.z; v.w = v.w * g.alpha + bv.w;
-            float* cp = C + (long)m * g.ldc + n;
-            if (full) {
-                if (rowbias && n < g.rb_cols) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(rowbias + (long)(m % g.rb_rows) * g.ldrb + n);
-                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-                }
-                if (g.bn_gamma) {
-                    const float sc = g.bn_gamma[m] / sqrtf(g.bn_var[m] + g.bn_eps), sh = g.bn_beta[m] - g.bn_mean[m] * sc;
-                    v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
-                }
-                if (g.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (g.drop_thr) {
-                    const unsigned rk = spot_row_key(g.drop_seed, (unsigned)(zb * g.M + m));
-                    v.x = spot_keep(rk, n, g.drop_thr) ? v.x * g.drop_scale : 0.f;
-                    v.y = spot_keep(rk, n + 1, g.drop_thr) ? v.y * g.drop_scale : 0.f;
-                    v.z = spot_keep(rk, n + 2, g.drop_thr) ? v.z * g.drop_scale : 0.f;
-                    v.w = spot_keep(rk, n + 3, g.drop_thr) ? v.w * g.drop_scale : 0.f;
-                }
-                if (g.mask) {
-                    const float4 k4 = *reinterpret_cast<const float4*>(g.mask + (long)m * g.ldmask + n);
-                    v.x = k4.x > 0.f ? v.x : 0.f; v.y = k4.y > 0.f ? v.y : 0.f;
-                    v.z = k4.z > 0.f ? v.z : 0.f; v.w = k4.w > 0.f ? v.w : 0.f;
-                }
-                if (res) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(res + (long)m * g.ldres + n);
-                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-                }
-                if (g.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (g.accumulate) {
-                    float4 o = *reinterpret_cast<float4*>(cp);
-                    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-                    *reinterpret_cast<float4*>(cp) = o;
-                } else {
-                    *reinterpret_cast<float4*>(cp) = v;
-                }
-            } else {
-                float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (n + j >= g.N) break;
-                    float x = vv[j];
-                    if (rowbias && n + j < g.rb_cols) x += rowbias[(long)(m % g.rb_rows) * g.ldrb + n + j];
-                    if (g.bn_gamma) {
-                        const float sc = g.bn_gamma[m] / sqrtf(g.bn_var[m] + g.bn_eps);
-                        x = fmaf(x, sc, g.bn_beta[m] - g.bn_mean[m] * sc);
-                    }
-                    if (g.relu == 1) x = fmaxf(x, 0.f);
-                    if (g.drop_thr)
-                        x = spot_keep(spot_row_key(g.drop_seed, (unsigned)(zb * g.M + m)), n + j, g.drop_thr) ? x * g.drop_scale : 0.f;
-                    if (g.mask) x = g.mask[(long)m * g.ldmask + n + j] > 0.f ? x : 0.f;
-                    if (res) x += res[(long)m * g.ldres + n + j];
-                    if (g.relu == 2) x = fmaxf(x, 0.f);
-                    if (g.accumulate) cp[j] += x;
-                    else cp[j] = x;
-                }
-            }
-        }
+        slot ^= 1;
     }
+    __syncthreads();                                               // every wave has read the last stage
+    finish_tile<TS, ROWSUM>(g, acc, rs, do_rs, lds, m0, n0, zb, zs, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -750,6 +929,10 @@ __global__ __launch_bounds__(256, 2) void gemm_ks4_kernel(GemmArgs g) {
 int pick_tile(const GemmArgs& a, int batch, int forced) {
     if (forced == 128) return 2;
     if (forced == 64 || forced == 32) return 1;
+    // whole 64x64 tiles of aligned operands run on the ring kernel, where the small tile is never slower (five
+    // workgroups per CU hide each other's epilogues; measured equal on N = 2048 outputs, 10-25 % faster on N = 256 and
+    // wherever the epilogue reads a mask or a residual)
+    if (a.fast && a.precision == 0 && a.M % 64 == 0 && a.N % 64 == 0) return 1;
     auto wgs = [&](int b) { return (long)((a.M + b - 1) / b) * ((a.N + b - 1) / b) * batch * a.splitk; };
     const long CUS = 256;
     const long w128 = wgs(128);
@@ -762,9 +945,19 @@ int launch(const GemmArgs& a, int batch, int tile, bool aligned, hipStream_t str
     const int ts = pick_tile(a, batch, tile), b = 64 * ts;
     const int ntn = (a.N + b - 1) / b, ntm = (a.M + b - 1) / b;
     dim3 grid(ntm * ntn, 1, batch * a.splitk);
+    // whole tiles of aligned operands (every k tile whole and inside one segment): the ring kernel, unless the grid is
+    // so small that the deep-prefetch loop below is the better fit
+    const int nkt_split = ((a.K + BK - 1) / BK + a.splitk - 1) / a.splitk;
+    const bool deep = ts == 1 && aligned && a.fast && a.M % 64 == 0 && a.N % 64 == 0 && (long)grid.x * grid.z <= 512 &&
+                      nkt_split >= 3 && !a.rowsum;
+    const bool ring = a.fast && a.precision == 0 && tile != 32 && !deep && a.M % b == 0 && a.N % b == 0 &&
+                      a.lda < (1L << 22) && a.ldb < (1L << 22);
     if (LA == 0 && LB == 0 && a.rowsum) {      // the weight-gradient layout is the only one that asks for row sums
         constexpr bool RS = LA == 0 && LB == 0;
-        if (ts == 2) {
+        if (ring) {
+            if (ts == 2) gemm_ring_kernel<LA, LB, 2, RS><<<grid, 256, 0, stream>>>(a);
+            else gemm_ring_kernel<LA, LB, 1, RS><<<grid, 256, 0, stream>>>(a);
+        } else if (ts == 2) {
             if (aligned) gemm_kernel<LA, LB, true, 2, RS><<<grid, 256, 0, stream>>>(a);
             else gemm_kernel<LA, LB, false, 2, RS><<<grid, 256, 0, stream>>>(a);
         } else {
@@ -786,9 +979,13 @@ int launch(const GemmArgs& a, int batch, int tile, bool aligned, hipStream_t str
     }
     // a grid of at most two workgroups per CU whose tiles are all interior ones: the deep-prefetch loop (same
     // products in the same order, so the same bits)
-    const int nkt_split = ((a.K + BK - 1) / BK + a.splitk - 1) / a.splitk;
-    if (ts == 1 && aligned && a.fast && a.M % 64 == 0 && a.N % 64 == 0 && (long)grid.x * grid.z <= 512 && nkt_split >= 3) {
+    if (deep) {
         gemm_kernel<LA, LB, true, 1, false, 0, true><<<grid, 256, 0, stream>>>(a);
+        return 0;
+    }
+    if (ring) {
+        if (ts == 2) gemm_ring_kernel<LA, LB, 2, false><<<grid, 256, 0, stream>>>(a);
+        else gemm_ring_kernel<LA, LB, 1, false><<<grid, 256, 0, stream>>>(a);
         return 0;
     }
     if (ts == 2) {

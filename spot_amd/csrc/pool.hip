@@ -1,6 +1,7 @@
 // 3x3 / stride 2 / padding 1 max-pool of the ResNet stem (ltr/models/backbone/resnet.py:113,199), NCHW fp32,
 // forward and backward.  HBM-bound: the forward reads the map once and writes a quarter of it plus one byte per
-// output (which of the nine window positions won; the first maximum in row-major window order, as ATen picks);
+// output (which of the nine window positions won; the first maximum in row-major window order, and any NaN in the
+// window replaces the running maximum so that it reaches the output, both as ATen's `val > max || isnan(val)`);
 // the backward is a gather — an input pixel lies in 1, 2 or 4 windows and collects dy from those whose winner
 // it is — so it needs no atomics and writes dx exactly once.
 #include "common.h"
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
             for (int kx = 0; kx < 3; ++kx) {
                 const float val = v[2 * o + kx];
                 const bool inside = kx > 0 || o > 0 || c0 >= 0;
-                if (inside && val > m[o]) {
+                if (inside && (val > m[o] || val != val)) {
                     m[o] = val;
                     w[o] = ky * 3 + kx;
                 }
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_any_kernel(const float* __res
             const int c = 2 * ox - 1 + kx;
             if (c < 0 || c >= W) continue;
             const float val = xp[(long)r * W + c];
-            if (val > m) {
+            if (val > m || val != val) {
                 m = val;
                 w = ky * 3 + kx;
             }

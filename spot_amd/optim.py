@@ -118,6 +118,27 @@ class FlatAdamW(torch.optim.Optimizer):
         flat = sd.pop("flat", None)
         state = sd.get("state") or {}
         sd["state"] = {}
+        # validate everything first: a rejected checkpoint must leave the live moments and step count as they were
+        step = 0
+        if flat is None and state:
+            n = sum(len(g["params"]) for g in self.param_groups)
+            missing = [i for i in range(n) if i not in state]
+            if missing:
+                raise ValueError("FlatAdamW.load_state_dict: no state for parameters %s (a checkpoint of an optimizer "
+                                 "that skipped them?)" % missing[:8])
+            if any(state[i].get("max_exp_avg_sq") is not None for i in range(n)):
+                raise ValueError("FlatAdamW.load_state_dict: amsgrad state is not supported")
+            # one host read for all step counters (they may be device tensors)
+            raw = [state[i]["step"] for i in range(n)]
+            if all(torch.is_tensor(t) for t in raw):
+                values = torch.stack([t.detach().reshape(()).double() for t in raw]).tolist()
+            else:
+                values = [float(t) for t in raw]
+            steps = {int(v) for v in values}
+            if len(steps) != 1:
+                raise ValueError("FlatAdamW.load_state_dict: per-parameter step counts differ (%s); this optimizer "
+                                 "keeps one" % sorted(steps)[:8])
+            step = steps.pop()
         super().load_state_dict(sd)
         if flat is not None:
             self._step = int(flat["step"])
@@ -125,21 +146,9 @@ class FlatAdamW(torch.optim.Optimizer):
             self.exp_avg_sq.copy_(flat["exp_avg_sq"])
             return
         self.exp_avg.zero_(), self.exp_avg_sq.zero_()
-        self._step = 0
+        self._step = step
         if not state:
             return
-        views = self._moment_views()
-        missing = [i for i in range(len(views)) if i not in state]
-        if missing:
-            raise ValueError("FlatAdamW.load_state_dict: no state for parameters %s (a checkpoint of an optimizer that "
-                             "skipped them?)" % missing[:8])
-        steps = {int(float(state[i]["step"])) for i in range(len(views))}
-        if len(steps) != 1:
-            raise ValueError("FlatAdamW.load_state_dict: per-parameter step counts differ (%s); this optimizer keeps one"
-                             % sorted(steps)[:8])
-        if any(state[i].get("max_exp_avg_sq") is not None for i in range(len(views))):
-            raise ValueError("FlatAdamW.load_state_dict: amsgrad state is not supported")
-        for i, (m, v) in enumerate(views):
+        for i, (m, v) in enumerate(self._moment_views()):
             m.copy_(state[i]["exp_avg"])
             v.copy_(state[i]["exp_avg_sq"])
-        self._step = steps.pop()

@@ -821,6 +821,30 @@ def test_maxpool3x3s2_vs_torch(ops, B, C, H, W):
         assert torch.equal(ops.max_pool_3x3_s2(xt.to(DEV), pool).cpu(), yr.detach())
 
 
+@pytest.mark.parametrize("H,W", [(16, 16), (9, 11)])
+def test_maxpool3x3s2_propagates_nan_as_torch(ops, H, W):
+    """A NaN anywhere in a window reaches the output (the trainer's skip logic relies on non-finite values arriving at
+    the loss), and the gradient goes where nn.MaxPool2d sends it; both the vectorised and the any-size kernel."""
+    pool = torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+    xt = T(det_input("x", (2, 3, H, W), 3, -1, 1)).clone()
+    xt[0, 0, 4, 5] = float("nan")
+    xt[0, 1, 0, 0] = float("nan")
+    xt[1, 2, 3, 3] = float("nan")
+    xt[1, 2, 3, 4] = float("nan")                   # two in one window: the later one is the recorded winner
+    xt[1, 0, H - 1, W - 1] = float("inf")
+    dy = det_input("dy", (2, 3, (H - 1) // 2 + 1, (W - 1) // 2 + 1), 4, -1, 1)
+    xg = xt.to(DEV).requires_grad_()
+    y = ops.max_pool_3x3_s2(xg, pool)
+    y.backward(G(dy))
+    xr = xt.clone().requires_grad_()
+    yr = pool(xr)
+    yr.backward(T(dy))
+    assert torch.isnan(yr).sum() > 3
+    assert torch.equal(torch.isnan(y).cpu(), torch.isnan(yr))
+    assert torch.equal(torch.nan_to_num(y.detach(), nan=7.0).cpu(), torch.nan_to_num(yr.detach(), nan=7.0))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=0, atol=1e-6)
+
+
 def test_in_network_transforms_golden(golden):
     """Batched GrayScale / EllipseRotationAffine kernels against the reference's per-sample loop (golden draws)."""
     from spot_amd.transforms_in_net import EllipseRotationAffine, GrayScale

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--sup", type=int, default=8)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--attention", default="f32")
+    ap.add_argument("--products", default="f32")
     args = ap.parse_args()
     from spot_amd import fusion, lib, ops
     from spot_amd.tensordict import TensorDict

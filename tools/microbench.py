@@ -13,17 +13,35 @@ import torch  # noqa: E402
 from spot_amd import lib, ops  # noqa: E402
 
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=20, warm=3, rounds=5):
+    """Median over `rounds` timed runs of `iters` launches each (seconds per launch).  The first timed run of a process
+    is preceded by ~30 ms of the same launches: the clocks take about that long to come up from idle, and a kernel
+    timed before then reads 10-15 % slow."""
+    global _WARM
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    if not _WARM:
+        import time
+        t0 = time.time()
+        while time.time() - t0 < 0.03:
+            fn()
+            torch.cuda.synchronize()
+        _WARM = True
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters * 1e-3
+    ts = []
+    for _ in range(rounds):
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) / iters * 1e-3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+_WARM = False
 
 
 def r(*shape):
@@ -70,8 +88,12 @@ def bench_gemm():
             kw.update(batch=batch, strideA=M * K, strideC=M * N)
         t = timeit(lambda: ops.gemm(A, Bm, Cc, M, N, K, transA=ta, transB=tb, **kw))
         fl = 2.0 * M * N * K * batch
-        print("%s M=%6d N=%5d K=%6d  %8.1f us  %6.1f TF  %s" % (name, M, N, K, t * 1e6, fl / t / 1e12,
-                                                               "sk=%d" % kw["splitk"] if "splitk" in kw else ""))
+        extra = ""
+        if os.environ.get("SPOT_MB_TILES"):
+            extra = "  | tile 64: %7.1f us  tile 128: %7.1f us" % tuple(
+                timeit(lambda: ops.gemm(A, Bm, Cc, M, N, K, transA=ta, transB=tb, tile=tl, **kw)) * 1e6 for tl in (64, 128))
+        print("%s M=%6d N=%5d K=%6d  %8.1f us  %6.1f TF  %s%s" % (name, M, N, K, t * 1e6, fl / t / 1e12,
+                                                                 "sk=%d" % kw["splitk"] if "splitk" in kw else "", extra))
 
 
 def bench_gemm_bf16x3():
