@@ -65,34 +65,43 @@ def position_embedding_sine(mask, num_pos_feats=128, temperature=10000.0):
 # --------------------------------------------------------------------------
 # backbone: ResNet-50 to layer3 (ltr/models/backbone/resnet.py:56-92,95-112,174-203)
 # --------------------------------------------------------------------------
-def _bn(x, sd, p, training):
+def _bn(x, sd, p, training, stats=None):
+    """nn.BatchNorm2d (resnet.py:66-90 uses the module default: momentum 0.1, eps 1e-5).  In training mode with a
+    `stats` dict, the running statistics move as the module's buffers do (copies kept in `stats`, `sd` untouched)."""
+    if training and stats is not None:
+        for leaf in (".running_mean", ".running_var", ".num_batches_tracked"):
+            if p + leaf not in stats:
+                stats[p + leaf] = sd[p + leaf].clone()
+        stats[p + ".num_batches_tracked"] += 1
+        return F.batch_norm(x, stats[p + ".running_mean"], stats[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                            training=True, momentum=0.1, eps=1e-5)
     return F.batch_norm(x, None if training else sd[p + ".running_mean"],
                         None if training else sd[p + ".running_var"],
                         sd[p + ".weight"], sd[p + ".bias"], training=training, eps=1e-5)
 
 
-def _bottleneck(x, sd, p, stride, dilation, training):
-    out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"]), sd, p + ".bn1", training))
+def _bottleneck(x, sd, p, stride, dilation, training, stats=None):
+    out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"]), sd, p + ".bn1", training, stats))
     out = F.conv2d(out, sd[p + ".conv2.weight"], stride=stride, padding=dilation, dilation=dilation)
-    out = F.relu(_bn(out, sd, p + ".bn2", training))
-    out = _bn(F.conv2d(out, sd[p + ".conv3.weight"]), sd, p + ".bn3", training)
+    out = F.relu(_bn(out, sd, p + ".bn2", training, stats))
+    out = _bn(F.conv2d(out, sd[p + ".conv3.weight"]), sd, p + ".bn3", training, stats)
     if (p + ".downsample.0.weight") in sd:
         x = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride), sd,
-                p + ".downsample.1", training)
+                p + ".downsample.1", training, stats)
     return F.relu(out + x)
 
 
-def resnet50_layer3(x, sd, prefix="backbone.0.body", training=False):
+def resnet50_layer3(x, sd, prefix="backbone.0.body", training=False, stats=None):
     """conv1/bn/relu/maxpool, layer1 (3), layer2 (4, stride 2), layer3 (6, stride 1;
     first block dilation 2, the rest dilation 1 — resnet.py:112,152-167) -> [B,1024,H/8,W/8]."""
     p = prefix
-    x = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], stride=2, padding=3), sd, p + ".bn1", training))
+    x = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], stride=2, padding=3), sd, p + ".bn1", training, stats))
     x = F.max_pool2d(x, 3, 2, 1)
     for name, nblk, stride, dil in (("layer1", 3, 1, 1), ("layer2", 4, 2, 1), ("layer3", 6, 1, 2)):
         for b in range(nblk):
             first = b == 0
             x = _bottleneck(x, sd, "%s.%s.%d" % (p, name, b), stride if first else 1,
-                            dil if first else 1, training)
+                            dil if first else 1, training, stats)
     return x
 
 
@@ -180,12 +189,12 @@ def mlp(x, sd, p, nlayers=3):
     return x
 
 
-def transt_features(img, sd, training=False):
+def transt_features(img, sd, training=False, stats=None):
     """Joiner + input_proj (transt_backbone.py:62-70,89-98; transt_model.py:270-275).
 
     Full-size crops: the padding mask is all False (misc.py:283-300 with equal sizes).
     """
-    f = resnet50_layer3(img, sd, "backbone.0.body", training)
+    f = resnet50_layer3(img, sd, "backbone.0.body", training, stats)
     B, _, H, W = f.shape
     mask = torch.zeros(B, H, W, dtype=torch.bool)
     pos = position_embedding_sine(mask, sd["input_proj.weight"].shape[0] // 2)
@@ -203,12 +212,14 @@ def transt_heads(hs, sd, b_iou=None):
 
 
 def transt_forward(template_u8, search_u8, sd, nhead=8, nlayers=4, b_iou=None, training=False,
-                   mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
-    """TransT.forward for one (template, search) batch (transt_model.py:229-293), no augmentation."""
+                   mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), stats=None):
+    """TransT.forward for one (template, search) batch (transt_model.py:229-293), no augmentation.  `training`:
+    batch-statistics BatchNorm; with a `stats` dict the BatchNorm buffers after the pass are left in it (the search
+    pass runs first, then the template pass, as transt_model.py:270-271 orders them)."""
     z, _ = preprocess(template_u8, torch.zeros(template_u8.shape[0], 3), mean, std)
     x, _ = preprocess(search_u8, torch.zeros(search_u8.shape[0], 3), mean, std)
-    src_s, mask_s, pos_s = transt_features(x, sd, training)
-    src_t, mask_t, pos_t = transt_features(z, sd, training)
+    src_s, mask_s, pos_s = transt_features(x, sd, training, stats)
+    src_t, mask_t, pos_t = transt_features(z, sd, training, stats)
     hs = fusion_network(src_t, mask_t, src_s, mask_s, pos_t, pos_s, sd, "featurefusion_network",
                         nhead, nlayers)
     return transt_heads(hs, sd, b_iou if b_iou is not None else search_u8.shape[0])
@@ -387,6 +398,14 @@ def build_target(anno_xywh_px, w, h):
     """_build_targets (transt_sparse_actor.py:203-224): xywh px -> normalised cxcywh."""
     a = anno_xywh_px
     return torch.stack([(a[:, 0] + a[:, 2] / 2) / w, (a[:, 1] + a[:, 3] / 2) / h, a[:, 2] / w, a[:, 3] / h], dim=1)
+
+
+def burnin_loss(out, search_anno, weight_dict, eos_coef=0.0625, search_hw=(256, 256)):
+    """_burnin_training (transt_sparse_actor.py:100-138): the supervised criterion (with the IoU-prediction term) on
+    labelled pairs only; returns the weighted loss and the reference's loss dict."""
+    h, w = search_hw
+    ld = criterion(out["logits"], out["boxes"], out.get("ious"), build_target(search_anno, w, h), eos_coef, "sup")
+    return sum(ld[k] * weight_dict[k + "_sup"] for k in ld if k + "_sup" in weight_dict), ld
 
 
 def sp_training_loss(out_sup, out_unsup, search_anno, aug_anno, weight_dict, eos_coef=0.0625,

@@ -45,6 +45,7 @@ class Settings:
         self.device = "cuda"
         self.batch_size_sup, self.batch_size_unsup = 8, 24
         self.teacher_update_frequency, self.keep_rate = 5, 0.998
+        self.burn_in_epochs, self.train_epoch_interval = 50, 1
         self.normalize_mean = [0.485, 0.456, 0.406]
         self.normalize_std = [0.229, 0.224, 0.225]
         self.search_feature_sz, self.template_feature_sz = 32, 16

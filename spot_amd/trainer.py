@@ -1,6 +1,7 @@
 """Sparsely-supervised training loop (hot loop only) on the HIP kernels.
 
-Host mirror of ltr/trainers/ltr_sparse_trainer.py:90-140,242-377: per iteration
+Host mirror of ltr/trainers/ltr_sparse_trainer.py:49-181,242-377: the burn-in stage (student alone on labelled pairs)
+and, per iteration of the sparsely-supervised stage,
   teacher EMA every `teacher_update_frequency` iterations -> teacher pseudo-labels
   -> middleware filter -> keep/refill compaction -> student step.
 Checkpointing, tensorboard and the DataLoader assembly of the reference are out
@@ -65,6 +66,66 @@ class LTRSparseTrainer:
         self._prefetched = None
         self._teacher_stream = None
         self._masks = {}
+
+    # -- the two stages of an epoch ----------------------------------------------
+    def train_epoch(self):
+        """One epoch (ltr_sparse_trainer.py:142-181): burn-in on labelled pairs only up to `burn_in_epochs`; the first
+        epoch after it copies the student into the teacher (keep rate 0); from then on the sparsely-supervised loop.
+        `loader_assemble` provides the loaders as the reference's does (init_burnin_loader / loader_burnin,
+        init_sparse_supervised_loader / loader_sup / loader_unsup)."""
+        self.epoch += 1
+        interval = getattr(self.settings, "train_epoch_interval", 1)
+        if self.epoch <= self.settings.burn_in_epochs:
+            if self.epoch % interval == 0:
+                self.loader_assemble.init_burnin_loader(self.epoch)
+                return self.cycle_dataset_burnin(self.loader_assemble.loader_burnin)
+            return None
+        if self.epoch == self.settings.burn_in_epochs + 1:
+            self._teacher_model_update(keep_rate=0)
+        if self.epoch % interval == 0:
+            self.loader_assemble.init_sparse_supervised_loader(self.epoch)
+            return self.cycle_dataset_sparse_supervised(self.loader_assemble.loader_sup, self.loader_assemble.loader_unsup)
+        return None
+
+    def cycle_dataset_burnin(self, loader, training=True):
+        """Burn-in stage (ltr_sparse_trainer.py:49-88): the student alone on labelled pairs."""
+        self.num_frames, self.start_time = 0, time.time()
+        last = None
+        for data in loader:
+            stats = self.burnin_iteration(data, training)
+            last = stats if stats is not None else last
+        return last
+
+    def burnin_iteration(self, data, training=True):
+        """One burn-in step: forward with no strong augmentation (masks all False, :264-269), skip on a non-finite
+        loss (:270-273, made rank-consistent), backward, gradient exchange, clipping for the Siamese variant, step."""
+        if self.move_data_to_gpu:
+            data = data.to(self.device, non_blocking=True)
+        if training:
+            self.arena.zero_grad()
+        loss, stats = self._burnin_training(data, training)
+        finite = bool(torch.isfinite(loss.detach()).item())
+        if not all_ranks_ok(finite, self.device):
+            self.skipped += 1
+            return None
+        if training:
+            self.reducer.arm()
+            loss.backward()
+            self.reducer.finish()
+            if self.clip_grad_norm:
+                norm = ops.clip_grad_norm_(self.arena.grad_flat, float(self.clip_grad_norm))
+                if not all_ranks_ok(math.isfinite(norm.item()), self.device):
+                    self.skipped += 1
+                    return None
+            self.optimizer.step()
+        self.num_frames += data["search_anno"].shape[0]
+        return stats
+
+    def _burnin_training(self, data, training=True):
+        self.actor.train(training)
+        with torch.set_grad_enabled(training):
+            data["masks"] = self._mask(data["search_anno"].shape[0], False)
+            return self.actor(mode="burnin", burnin_data=data)
 
     # -- one epoch over the two loaders ----------------------------------------
     def cycle_dataset_sparse_supervised(self, loader_sup, loader_unsup, training=True):

@@ -1009,6 +1009,94 @@ def case_student(seed=3):
          gn_keys=list(allnorm.keys()), gn_vals=list(allnorm.values()), **out)
 
 
+def case_teacher_train_b32(B=32, seed=1):
+    """G23: the 32-clip pseudo-labelling pass with the teacher left in the module-default train() mode, as the
+    reference's trainer leaves it (base_sparse_actor.py:42-49 only toggles the student): batch-statistics BatchNorm
+    in both backbone passes (whose running statistics move as a side effect) through the teacher_data branch of
+    transt_model.py:229-293, then transt_sparse_actor.py:35-98 and the middleware.  Dropout is 0 so that the case is
+    deterministic.  Besides the outputs, a few BatchNorm buffers after the pass are kept."""
+    import ltr.actor as actors
+    from ltr.utils import TensorDict
+    S = Settings()
+    net = build_transt(S, seed=seed, dropout=0.0).train()
+    actor = actors.TranstSparseActor(settings=S, student_net=net, teacher_net=net, objective=None)
+    d = teacher_inputs(B, seed)
+
+    def run():
+        data = TensorDict({k: torch.from_numpy(v.copy()) for k, v in d.items()})
+        data["masks"] = torch.zeros(B, dtype=torch.bool)
+        raw = net(teacher_data=data)
+        raw = {k: v.clone() for k, v in raw.items()}
+        return raw, actor._decode_teacher_result(data, {k: v.clone() for k, v in raw.items()})
+
+    start = {k: v.clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        _, pseudo0 = run()
+        conf = pseudo0["best_conf"]
+        lg = np.sort(t2n(torch.log(conf / (1 - conf))).astype(np.float64))
+        lo, hi = 6, B - 7                            # the widest gap that leaves at least 7 clips on either side
+        j = lo + int(np.argmax(lg[lo + 1:hi + 1] - lg[lo:hi]))
+        det_shift = np.float32(np.log(0.85 / 0.15) - 0.5 * (lg[j] + lg[j + 1]))
+        print("confidence logits: spread %.4f, chosen gap %.5f after %d clips" % (lg[-1] - lg[0], lg[j + 1] - lg[j], j + 1))
+        net.load_state_dict(start)                   # the calibration pass moved the running statistics: start over
+        net.iou_embed.layers[2].bias += det_shift
+        raw, pseudo = run()
+    gap = float((pseudo["best_conf"] - 0.85).abs().min())
+    print("closest confidence to tau: %.2e (relative tolerance of the parity tests: 1e-3)" % gap)
+    res = run_middleware(S, middle_inputs(B, seed), pseudo)
+    assert 0 < int(res["aug_success"].sum()) < B
+    sd = net.state_dict()
+    bn = {}
+    for k in ("backbone.0.body.bn1", "backbone.0.body.layer1.0.downsample.1", "backbone.0.body.layer2.3.bn2",
+              "backbone.0.body.layer3.5.bn3"):
+        bn["bn." + k + ".running_mean"] = t2n(sd[k + ".running_mean"])
+        bn["bn." + k + ".running_var"] = t2n(sd[k + ".running_var"])
+        bn["bn." + k + ".num_batches_tracked"] = t2n(sd[k + ".num_batches_tracked"])
+    st = 4
+    save("g23_teacher_train_b32", seed=seed, B=B, iou_bias_shift=det_shift, slice_step=st,
+         pred_logits=t2n(raw["pred_logits"])[:, ::st], pred_boxes=t2n(raw["pred_boxes"])[:, ::st],
+         pred_ious=t2n(raw["pred_ious"])[:, ::st],
+         best_bbox=t2n(pseudo["best_bbox"]), best_score=t2n(pseudo["best_score"]), best_conf=t2n(pseudo["best_conf"]),
+         aug_anno=t2n(res["aug_anno"]), aug_success=t2n(res["aug_success"]), **bn)
+
+
+def case_burnin(seed=7, bs=4):
+    """G24: one burn-in step, actor(mode="burnin") (transt_sparse_actor.py:100-138) as the trainer's burn-in cycle
+    calls it (ltr_sparse_trainer.py:255-275: masks all False): student forward on labelled pairs only, targets,
+    the supervised criterion with the IoU-prediction term, the weighted loss, its statistics and its gradients (train
+    mode, dropout 0, joint transform configured with probability 0 as in case_student)."""
+    import ltr.actor as actors
+    from ltr.models.pre_input import GrayScale, JointTransform
+    from ltr.models.tracking.transt_criterion import transt_loss
+    from ltr.utils import TensorDict
+    S = Settings()
+    net = build_transt(S, seed=seed, dropout=0.0).train()
+    net.joint_trans = JointTransform([GrayScale(gray_probability=0.0)])
+    actor = actors.TranstSparseActor(settings=S, student_net=net, teacher_net=net, objective=transt_loss(S))
+    d = TensorDict()
+    d["template_images"] = torch.from_numpy(det_input("template_img", (bs, 3, 128, 128), seed, 0, 256, np.uint8))
+    d["search_images"] = torch.from_numpy(det_input("search_img", (bs, 3, 256, 256), seed, 0, 256, np.uint8))
+    d["template_avg"] = torch.from_numpy(det_input("template_avg", (bs, 3), seed, 0, 255))
+    d["search_avg"] = torch.from_numpy(det_input("search_avg", (bs, 3), seed, 0, 255))
+    d["template_anno"] = torch.from_numpy(det_input("template_anno", (bs, 4), seed, 20, 60))
+    xy, wh = det_input("search_xy", (bs, 2), seed, 30, 120), det_input("search_wh", (bs, 2), seed, 30, 100)
+    d["search_anno"] = torch.from_numpy(np.concatenate([xy, wh], -1).astype(np.float32))
+    d["masks"] = torch.zeros(bs, dtype=torch.bool)
+    search_anno = t2n(d["search_anno"]).copy()
+    loss, stats = actor(mode="burnin", burnin_data=d)
+    loss.backward()
+    sd = dict(net.named_parameters())
+    out = {}
+    for k, p_ in sd.items():
+        if p_.grad is not None and k.startswith(("featurefusion_network.", "class_embed.", "bbox_embed.", "iou_embed.",
+                                                 "input_proj.")):
+            g = t2n(p_.grad).reshape(-1)
+            out["gsub." + k] = g[::max(1, g.size // 2048)]
+    allnorm = {k: float(np.linalg.norm(t2n(p.grad))) for k, p in sd.items() if p.grad is not None}
+    save("g24_burnin", seed=seed, bs=bs, loss=t2n(loss), search_anno=search_anno, stat_keys=list(stats.keys()),
+         stat_vals=[stats[k] for k in stats], gn_keys=list(allnorm.keys()), gn_vals=list(allnorm.values()), **out)
+
+
 CASES = {
     "fusion": case_fusion, "mha": case_mha, "layer_bwd": case_layer_bwd, "teacher": case_teacher,
     "decode": case_decode, "compaction": case_compaction, "boxes": case_boxes,
@@ -1016,6 +1104,7 @@ CASES = {
     "xcorr": case_xcorr, "ema": case_ema, "pre_pos": case_preprocess_posenc,
     "student": case_student, "transforms": case_transforms, "ocean": case_ocean, "ocean_tracker": case_ocean_tracker, "ocean_model": case_ocean_model, "crop": case_crop,
     "track": case_track, "matcher_offmap": case_matcher_offmap, "teacher_b32": case_teacher_b32,
+    "teacher_train_b32": case_teacher_train_b32, "burnin": case_burnin,
 }
 
 

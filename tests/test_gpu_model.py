@@ -112,6 +112,96 @@ def test_teacher_pseudo_label_pipeline_golden_at_benchmark_batch(golden, linear_
     np.testing.assert_allclose(res["aug_anno"].cpu().numpy(), g["aug_anno"], atol=0.5)
 
 
+def test_teacher_pseudo_label_pipeline_train_mode_golden_at_benchmark_batch(golden):
+    """The pass the benchmark times: the teacher left in the module-default train() mode, as the reference's trainer
+    leaves it (base_sparse_actor.py:42-49 toggles the student only) — batch-statistics BatchNorm in both backbone
+    passes, whose running statistics move — at 32 clips with dropout 0, against the reference run the same way:
+    maps, decoded boxes / scores / confidences, identical keep mask, and the BatchNorm buffers after the pass (the
+    template pass runs on the second stream with its buffer updates deferred: they must land as in the sequential
+    order)."""
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.middleware import SparseMiddleware
+    from spot_amd.tensordict import TensorDict
+    from tests.test_oracle_model import check_batchnorm_buffers, teacher_b32_inputs
+    g = golden("g23_teacher_train_b32")
+    B, seed, st = int(g["B"]), int(g["seed"]), int(g["slice_step"])
+    S = Settings(dropout=0.0)
+    net = build(seed, dropout=0.0).train()
+    with torch.no_grad():
+        net.iou_embed.layers[2].bias += float(g["iou_bias_shift"])
+    start = {k: v.clone() for k, v in net.state_dict().items()}
+    actor = TranstSparseActor(S, net, net, None)
+    key, unl, mid = teacher_b32_inputs(g)
+    data = TensorDict({"key_images": key.to(DEV), "unlabeled_images": unl.to(DEV),
+                       "key_avg": G(det_input("key_avg", (B, 3), seed, 0, 255)),
+                       "unlabeled_avg": G(det_input("unlabeled_avg", (B, 3), seed, 0, 255)),
+                       "key_anno": G(det_input("key_anno", (B, 4), seed, 20, 80)),
+                       "unlabeled_anno": G(det_input("unlabeled_anno", (B, 4), seed, 40, 120))})
+    with torch.no_grad():
+        raw = net(teacher_data=TensorDict(data))
+    assert net.training
+    np.testing.assert_allclose(raw["pred_logits"].cpu().numpy()[:, ::st], g["pred_logits"], rtol=1e-3, atol=5e-4)
+    np.testing.assert_allclose(raw["pred_boxes"].cpu().numpy()[:, ::st], g["pred_boxes"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(raw["pred_ious"].cpu().numpy()[:, ::st], g["pred_ious"], rtol=1e-3, atol=1e-4)
+    check_batchnorm_buffers(g, net.state_dict())
+    net.load_state_dict(start)                      # the actor's pass below starts from the same buffers
+    pseudo = actor(mode="inference", teacher_data=TensorDict(data))
+    np.testing.assert_allclose(pseudo["best_bbox"].cpu().numpy(), g["best_bbox"], atol=0.5)       # 0.5 px
+    np.testing.assert_allclose(pseudo["best_score"].cpu().numpy(), g["best_score"], rtol=1e-3)
+    np.testing.assert_allclose(pseudo["best_conf"].cpu().numpy(), g["best_conf"], rtol=1e-3)
+    res = SparseMiddleware(S).record_relay_results(mid, pseudo)
+    assert np.array_equal(res["aug_success"].cpu().numpy(), g["aug_success"])                     # identical keep mask
+    assert 0 < int(g["aug_success"].sum()) < B
+    np.testing.assert_allclose(res["aug_anno"].cpu().numpy(), g["aug_anno"], atol=0.5)
+
+
+def test_burnin_step_golden(golden):
+    """actor(mode="burnin") (transt_sparse_actor.py:100-138) against the reference: loss, every statistic, every
+    gradient norm and the gradient samples of the fusion network and the heads; then the trainer's burn-in cycle
+    (ltr_sparse_trainer.py:49-88,255-275) takes the same step: masks all False, backward, optimizer step."""
+    from spot_amd.actor import TranstSparseActor
+    from spot_amd.criterion import transt_loss
+    from spot_amd.middleware import SparseMiddleware
+    from spot_amd.tensordict import TensorDict
+    from spot_amd.trainer import LTRSparseTrainer
+    from tests.test_oracle_model import burnin_batch, check_gradient_samples
+    g = golden("g24_burnin")
+    seed, bs = int(g["seed"]), int(g["bs"])
+    S = Settings(dropout=0.0, batch_size_sup=bs, batch_size=bs)
+    net = build(seed, dropout=0.0).train()
+    actor = TranstSparseActor(S, net, net, transt_loss(S))
+    batch = lambda: TensorDict({k: v.to(DEV) for k, v in burnin_batch(seed, bs).items()})
+    data = batch()
+    data["masks"] = torch.zeros(bs, dtype=torch.bool, device=DEV)
+    loss, stats = actor(mode="burnin", burnin_data=data)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-3)
+    stats = actor.stats_to_float(stats)
+    ref_stats = dict(zip([str(k) for k in g["stat_keys"]], g["stat_vals"]))
+    assert set(stats) == set(ref_stats)
+    for k, v in ref_stats.items():
+        np.testing.assert_allclose(stats[k], v, rtol=2e-3, atol=1e-5, err_msg=k)
+    loss.backward()
+    gn = dict(zip([str(k) for k in g["gn_keys"]], g["gn_vals"]))
+    params = dict(net.named_parameters())
+    worst = max(abs(float(p.grad.norm()) - gn[k]) / gn[k] for k, p in params.items() if gn.get(k, 0) > 1e-6)
+    assert worst < 2e-2, worst
+    check_gradient_samples(g, {k: p.grad for k, p in params.items() if p.grad is not None})
+    # the trainer's burn-in cycle on the same batch: one optimizer step along the golden's gradient
+    net2 = build(seed, dropout=0.0).train()
+    before = {k: p.detach().clone() for k, p in net2.named_parameters()}
+    actor2 = TranstSparseActor(S, net2, net2, transt_loss(S))
+    opt = torch.optim.SGD(net2.parameters(), lr=1e-3)
+    trainer = LTRSparseTrainer(actor2, None, opt, S, SparseMiddleware(S))
+    out = trainer.cycle_dataset_burnin([batch()])
+    np.testing.assert_allclose(float(out["Loss/total"]), float(g["loss"]), rtol=1e-3)
+    assert trainer.num_frames == bs and trainer.skipped == 0
+    for k in ("class_embed.layers.2.weight", "featurefusion_network.decoder.layers.0.linear2.weight"):
+        step = (before[k] - dict(net2.named_parameters())[k].detach()) / 1e-3
+        ref = params[k].grad
+        cos = float((step * ref).sum() / (step.norm() * ref.norm()))
+        assert cos > 0.9999, (k, cos)
+
+
 def test_sharded_pseudo_labelling_equals_single_batch():
     """Pseudo-labelling + filtering of a clip set cut into contiguous per-rank blocks (dist.shard_range) gives the
     result of one big batch: the teacher runs in eval mode, so clips do not interact and no collective is needed."""

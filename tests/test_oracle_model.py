@@ -169,6 +169,84 @@ def test_teacher_pipeline_golden_at_benchmark_batch(golden):
     np.testing.assert_allclose(res["aug_anno"].numpy(), g["aug_anno"], atol=0.5)
 
 
+def test_teacher_pipeline_train_mode_golden_at_benchmark_batch(golden):
+    """The same 32-clip pass with the teacher in train() mode (the mode the reference's trainer leaves it in, and the
+    one the benchmark times): batch-statistics BatchNorm in both backbone passes, dropout 0; outputs, keep mask and
+    the BatchNorm buffers after the pass."""
+    g = golden("g23_teacher_train_b32")
+    B, seed, st = int(g["B"]), int(g["seed"]), int(g["slice_step"])
+    sd = model_sd(seed)
+    sd["iou_embed.layers.2.bias"] = sd["iou_embed.layers.2.bias"] + float(g["iou_bias_shift"])
+    key, unl, mid = teacher_b32_inputs(g)
+    stats = {}
+    with torch.no_grad():
+        out = O.transt_forward(key, unl, sd, training=True, stats=stats)
+    np.testing.assert_allclose(out["pred_logits"].numpy()[:, ::st], g["pred_logits"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(out["pred_boxes"].numpy()[:, ::st], g["pred_boxes"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(out["pred_ious"].numpy()[:, ::st], g["pred_ious"], rtol=1e-3, atol=1e-4)
+    dec = O.decode_teacher(out["pred_logits"], out["pred_boxes"], out["pred_ious"], 0.40, 32, 256, 256)
+    np.testing.assert_allclose(dec["best_bbox"].numpy(), g["best_bbox"], atol=0.5)
+    np.testing.assert_allclose(dec["best_score"].numpy(), g["best_score"], rtol=1e-3)
+    np.testing.assert_allclose(dec["best_conf"].numpy(), g["best_conf"], rtol=1e-3)
+    res = O.middleware_filter(dec["best_bbox"], dec["best_conf"], mid["unlabeled_box_extract"],
+                              mid["unlabeled_resize_factors"], mid["aug_box_extract"], mid["aug_resize_factors"], 256, 0.85)
+    assert np.array_equal(res["aug_success"].numpy(), g["aug_success"])
+    assert 0 < int(g["aug_success"].sum()) < B
+    np.testing.assert_allclose(res["aug_anno"].numpy(), g["aug_anno"], atol=0.5)
+    check_batchnorm_buffers(g, stats)
+
+
+def check_batchnorm_buffers(g, buffers):
+    """The golden's `bn.<layer>.<buffer>` entries against `buffers` (name -> tensor): two passes (search, template)
+    have moved every layer's running statistics once each."""
+    names = [n[len("bn."):] for n in g.files if n.startswith("bn.")]
+    assert len(names) == 12
+    for k in names:
+        got = buffers[k].detach().cpu().numpy()
+        if k.endswith("num_batches_tracked"):
+            assert int(got) == int(g["bn." + k]) == 2, k
+        else:
+            np.testing.assert_allclose(got, g["bn." + k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def burnin_batch(seed, bs):
+    d = {"template_images": T(det_input("template_img", (bs, 3, 128, 128), seed, 0, 256, np.uint8)),
+         "search_images": T(det_input("search_img", (bs, 3, 256, 256), seed, 0, 256, np.uint8)),
+         "template_avg": T(det_input("template_avg", (bs, 3), seed, 0, 255)),
+         "search_avg": T(det_input("search_avg", (bs, 3), seed, 0, 255)),
+         "template_anno": T(det_input("template_anno", (bs, 4), seed, 20, 60))}
+    xy, wh = det_input("search_xy", (bs, 2), seed, 30, 120), det_input("search_wh", (bs, 2), seed, 30, 100)
+    d["search_anno"] = T(np.concatenate([xy, wh], -1).astype(np.float32))
+    return d
+
+
+BURNIN_STATS = {"Loss/ce": "loss_ce", "Loss/bbox": "loss_bbox", "Loss/giou": "loss_giou", "iou": "iou",
+                "Loss/iou_pred": "loss_iou_pred"}
+
+
+def test_burnin_step_golden(golden):
+    """actor(mode="burnin") of the reference: loss, every statistic, every gradient norm and the gradient samples."""
+    g = golden("g24_burnin")
+    seed, bs = int(g["seed"]), int(g["bs"])
+    sd = model_sd(seed, requires_grad=True)
+    d = burnin_batch(seed, bs)
+    np.testing.assert_array_equal(d["search_anno"].numpy(), g["search_anno"])
+    out = O.transt_forward(d["template_images"], d["search_images"], sd, b_iou=bs, training=True)
+    loss, ld = O.burnin_loss({"logits": out["pred_logits"], "boxes": out["pred_boxes"], "ious": out["pred_ious"]},
+                             d["search_anno"], Settings().weight_dict)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-3)
+    ref_stats = dict(zip([str(k) for k in g["stat_keys"]], g["stat_vals"]))
+    assert set(ref_stats) == set(BURNIN_STATS) | {"Loss/total"}
+    for name, key in BURNIN_STATS.items():
+        np.testing.assert_allclose(ld[key].item(), ref_stats[name], rtol=2e-3, atol=1e-5, err_msg=name)
+    loss.backward()
+    gn = dict(zip([str(k) for k in g["gn_keys"]], g["gn_vals"]))
+    worst = max(abs(float(v.grad.norm()) - gn[k]) / gn[k] for k, v in sd.items()
+                if v.requires_grad and v.grad is not None and gn.get(k, 0) > 1e-6)
+    assert worst < 2e-2, worst
+    check_gradient_samples(g, {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None})
+
+
 def test_online_template_track_golden(golden):
     """TransT.template / TransT.track at the network boundary and the tracker's state update over five frames."""
     g = golden("g21_track")
