@@ -363,7 +363,9 @@ int spot_mha_fwd_splitk_f32(const float* q, long ldq, const float* k, long ldk, 
  * held by every GPU the library runs on until the process ends); a call needing more, i.e.
  * spot_mha_fwd_splitk_ws_floats(B, Lq, nhead, nsplit) > SPOT_MHA_SPLITK_NOALLOC_MAX_FLOATS, is rejected.  The call
  * makes no hipMalloc / hipFree.  Same results as spot_mha_fwd_splitk_f32 bit for bit.  Calls that overlap on one GPU
- * (two streams, two threads) share the array and race: serialise them. */
+ * (two streams, two threads) share the array and race: serialise them.  The FIRST call on a device resolves the
+ * array's address (hipGetDevice + hipGetSymbolAddress, which may load the code object): make one eager call per
+ * device before any stream capture; a first call made while capturing can invalidate the capture. */
 #define SPOT_MHA_SPLITK_NOALLOC_MAX_FLOATS 2228224L   /* 8 key ranges x 8 heads x 1024 queries x (32 + 2) */
 int spot_mha_fwd_splitk_noalloc_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                     float* out, long ldo, const unsigned char* key_padding_mask, int nsplit, int B,

@@ -1195,6 +1195,29 @@ def test_gemm_small_grid_kernels_against_float64(ops):
     out = torch.zeros(128, 128, device=DEV)
     ops.gemm(A, W, out, 128, 128, 288, splitk=4, accumulate=True)
     np.testing.assert_allclose(out.cpu().double().numpy(), (A.double() @ W.double().T).cpu().numpy(), rtol=1e-5, atol=2e-4)
+    # the same empty range in the bf16x3 loop (its own prefetch code)
+    out3 = torch.zeros(128, 128, device=DEV)
+    ops.gemm(A, W, out3, 128, 128, 288, splitk=4, accumulate=True, precision=1)
+    np.testing.assert_allclose(out3.cpu().double().numpy(), (A.double() @ W.double().T).cpu().numpy(), rtol=1e-5, atol=2e-4)
+    # tile = 32 re-implements the epilogue: inference BatchNorm over the rows, dropout and K segments against tile = 64
+    M, N, K = 128, 256, 512
+    A2 = G(rng.standard_normal((2, M, K // 2)).astype(np.float32))          # two K segments, 256 apart in k
+    W2 = G(rng.standard_normal((N, K)).astype(np.float32))
+    bn = [G(rng.standard_normal(M).astype(np.float32)) for _ in range(3)] + [G((rng.random(M) + 0.5).astype(np.float32))]
+    outs = {}
+    for tile in (32, 64):
+        o = torch.empty(M, N, device=DEV)
+        ops.gemm(A2, W2, o, M, N, K, lda=K // 2, kseg=K // 2, segA=M * (K // 2), segB=K // 2, relu=True, drop_p=0.25, drop_seed=99,
+                 bn=(bn[0], bn[1], bn[2], bn[3], 1e-5), tile=tile)
+        outs[tile] = o
+    assert float((outs[32] == 0).float().mean()) > 0.3                        # relu and dropout both took effect
+    assert torch.equal(outs[32] == 0, outs[64] == 0)                          # same mask
+    np.testing.assert_allclose(outs[32].cpu().numpy(), outs[64].cpu().numpy(), rtol=1e-5, atol=1e-4)
+    ref = torch.cat([A2[0], A2[1]], 1).double() @ W2.double().T
+    sc = bn[0].double() / torch.sqrt(bn[3].double() + 1e-5)
+    ref = torch.relu(ref * sc[:, None] + (bn[1].double() - bn[2].double() * sc)[:, None]) / 0.75
+    kept = outs[64] != 0
+    np.testing.assert_allclose(outs[64][kept].cpu().double().numpy(), ref[kept].cpu().numpy(), rtol=1e-4, atol=2e-4)
     A, W, out = G(np.ones((64, 96), np.float32)), G(np.ones((64, 96), np.float32)), torch.empty(64, 64, device=DEV)
     with pytest.raises(RuntimeError, match="tile=32"):
         ops.gemm(A, W, out, 64, 64, 96, tile=32)
