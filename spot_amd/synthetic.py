@@ -26,6 +26,24 @@ def unsup_batch(B, seed, temp_sz=128, search_sz=256, device="cpu"):
     return d, m
 
 
+def unsup_clips(lo, hi, seed, block=32, device="cpu", **kw):
+    """Clips [lo, hi) of an unbounded synthetic clip set: the set is the concatenation of unsup_batch blocks of `block`
+    clips (block b seeded with (seed, b)), so any contiguous range can be produced without its predecessors and every
+    partition of a job over ranks sees the same clips."""
+    parts_d, parts_m = [], []
+    for b in range(lo // block, (hi + block - 1) // block if hi > lo else lo // block):
+        d, m = unsup_batch(block, seed * 100003 + b, device="cpu", **kw)
+        a, e = max(lo, b * block) - b * block, min(hi, (b + 1) * block) - b * block
+        parts_d.append({k: v[a:e] for k, v in d.items()})
+        parts_m.append({k: v[a:e] for k, v in m.items()})
+    if not parts_d:
+        d, m = unsup_batch(1, seed * 100003, device="cpu", **kw)
+        parts_d, parts_m = [{k: v[:0] for k, v in d.items()}], [{k: v[:0] for k, v in m.items()}]
+    data = TensorDict({k: torch.cat([p[k] for p in parts_d]).to(device) for k in parts_d[0]})
+    mid = {k: torch.cat([p[k] for p in parts_m]).to(device) for k in parts_m[0]}
+    return data, mid
+
+
 def sup_batch(B, seed, temp_sz=128, search_sz=256, device="cpu"):
     d = TensorDict()
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)

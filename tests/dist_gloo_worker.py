@@ -44,11 +44,25 @@ def part1(rank, world):
     for (k, t), o in zip(arena.f32, arena.offsets):          # every .grad must still be a view into the flat buffer
         if isinstance(t, torch.nn.Parameter):
             assert t.grad.data_ptr() == arena.grad_flat[o:].data_ptr(), k
+    # the same exchange with buckets launched from inside backward as soon as they are complete (overlap=True): the
+    # first armed backward of a process launches nothing early, the later ones do
+    net2 = model()
+    arena2 = ParamArena(net2)
+    red2 = GradBucketReducer(arena2, bucket_bytes=4096, overlap=True)
+    early = []
+    for _ in range(3):
+        arena2.zero_grad()
+        red2.arm()
+        net2(x).square().sum().backward()
+        early.append(list(red2.issued))                      # what went out before finish()
+        red2.finish()
+    grads_overlap = {k: p.grad.clone() for k, p in net2.named_parameters()}
     return {"grads": grads, "range": shard_range(1024, rank, world), "ok_all": all_ranks_ok(True, "cpu"),
-            "ok_mixed": all_ranks_ok(rank == 0, "cpu")}
+            "ok_mixed": all_ranks_ok(rank == 0, "cpu"), "grads_overlap": grads_overlap, "early": early,
+            "issued_overlap": list(red2.issued), "n_buckets": len(red2.buckets)}
 
 
-def part2(rank, world):
+def part2(rank, world, overlap=False):
     from spot_amd.tensordict import TensorDict
     from spot_amd.trainer import LTRSparseTrainer
     from oracle import spot_oracle as O
@@ -91,6 +105,10 @@ def part2(rank, world):
     actor = Actor()
     opt = torch.optim.SGD(actor.student_net.parameters(), lr=0.1)
     trainer = Trainer(actor, None, opt, Settings(), None)
+    if overlap:
+        from spot_amd.dist import GradBucketReducer
+        trainer.reducer = GradBucketReducer(trainer.arena, bucket_bytes=4096, overlap=True)
+    issued = []
     rng = np.random.default_rng(100 + rank)
     log = []
     for i in range(4):
@@ -107,16 +125,18 @@ def part2(rank, world):
         stats = trainer.train_iteration(i, sup, unsup, mid)
         after = torch.cat([p.detach().flatten() for p in actor.student_net.parameters()])
         log.append({"stepped": stats is not None, "changed": not torch.equal(before, after)})
+        issued.append(list(trainer.reducer.issued))
     weights = torch.cat([p.detach().flatten() for p in actor.student_net.parameters()])
     running = actor.student_net[2].running_mean.clone()
-    return {"log": log, "weights": weights, "skipped": trainer.skipped, "running_mean": running}
+    return {"log": log, "weights": weights, "skipped": trainer.skipped, "running_mean": running, "issued": issued}
 
 
 def main():
     out = sys.argv[1]
     from spot_amd.dist import init_from_env
     rank, world, _ = init_from_env("gloo")
-    res = {"rank": rank, "world": world, "part1": part1(rank, world), "part2": part2(rank, world)}
+    res = {"rank": rank, "world": world, "part1": part1(rank, world), "part2": part2(rank, world),
+           "part2_overlap": part2(rank, world, overlap=True)}
     torch.save(res, out % rank)
     dist.destroy_process_group()
 

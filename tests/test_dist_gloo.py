@@ -37,6 +37,15 @@ def test_world2_bucketed_allreduce_and_trainer_iteration(tmp_path):
             torch.testing.assert_close(p1["grads"][k], v, rtol=1e-5, atol=1e-6)
         assert p1["ok_all"] is True and p1["ok_mixed"] is False
     assert res[0]["part1"]["range"] == (0, 512) and res[1]["part1"]["range"] == (512, 1024)
+    # ---- the same exchange with early launches (overlap=True): same averaged gradients as the plain exchange, the
+    # buckets go out from inside backward from the second armed backward on, in the same order on both ranks
+    for r in range(world):
+        p1 = res[r]["part1"]
+        for k, v in p1["grads"].items():
+            assert torch.equal(p1["grads_overlap"][k], v), k
+        assert p1["early"][0] == [] and len(p1["early"][1]) == p1["n_buckets"] and p1["early"][2] == p1["early"][1]
+        assert sorted(p1["issued_overlap"]) == list(range(p1["n_buckets"]))
+    assert res[0]["part1"]["issued_overlap"] == res[1]["part1"]["issued_overlap"]
     # ---- train_iteration: iteration 1 is skipped on BOTH ranks although only rank 1 had nothing to train on; the
     # other iterations step, and the students stay bit-identical because they only ever see averaged gradients
     for r in range(world):
@@ -46,6 +55,14 @@ def test_world2_bucketed_allreduce_and_trainer_iteration(tmp_path):
         assert p2["skipped"] == 1
     assert torch.equal(res[0]["part2"]["weights"], res[1]["part2"]["weights"])
     assert not torch.equal(res[0]["part2"]["running_mean"], res[1]["part2"]["running_mean"])   # BatchNorm stays per rank
+    # ---- the same four iterations with the gradient buckets launched from inside backward: same skip decisions, the
+    # same issue order on both ranks in every iteration, and weights equal to the plain exchange's bit for bit
+    for r in range(world):
+        po = res[r]["part2_overlap"]
+        assert [e["stepped"] for e in po["log"]] == [True, False, True, True] and po["skipped"] == 1
+        assert torch.equal(po["weights"], res[r]["part2"]["weights"])
+    assert res[0]["part2_overlap"]["issued"] == res[1]["part2_overlap"]["issued"]
+    assert all(len(i) > 1 for n, i in enumerate(res[0]["part2_overlap"]["issued"]) if n != 1)
 
 
 def test_launcher_reports_a_failing_rank():

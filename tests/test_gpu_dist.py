@@ -144,3 +144,48 @@ def test_bench_starts_its_own_ranks_two_rank_rehearsal(tmp_path):
     assert line["n_gpus"] == 2 and line["config"]["communicator_ranks"] == 2
     assert len(line["config"]["ms_per_step_per_rank"]) == 2 and line["value"] > 0
     assert line["ms_per_step"] >= max(line["config"]["ms_per_step_per_rank"]) - 1e-6
+
+
+def test_cfg3_sharded_pseudo_labelling_equals_single_batch():
+    """bench.py's cfg3 job (teacher pseudo-labelling + filter over a clip set sharded in contiguous rank blocks): one
+    rank labelling the whole set in passes of 32, three ranks labelling their blocks, and one batch holding every clip
+    all give the same labels bit for bit (the teacher is in eval(): clips do not interact, and no kernel on the path
+    chooses its arithmetic by batch size)."""
+    import bench
+    total = 96
+    whole = bench.Cfg3Job(total, total, 0, 1).step()                        # one network pass over all clips
+    passes = bench.Cfg3Job(total, 32, 0, 1).step()                          # N = 1 as bench.py runs it
+    assert 0 < int(whole["aug_success"].sum()) < total
+    for k in bench.Cfg3Job.KEYS:
+        assert torch.equal(passes[k], whole[k]), k
+    shards = [bench.Cfg3Job(total, 32, r, 3) for r in range(3)]
+    assert [(j.lo, j.hi) for j in shards] == [(0, 32), (32, 64), (64, 96)]
+    parts = [j.step() for j in shards]
+    for k in bench.Cfg3Job.KEYS:
+        assert torch.equal(torch.cat([p[k] for p in parts]), whole[k]), k
+
+
+def test_bench_cfg3_two_rank_rehearsal():
+    """`python bench.py --config cfg3 --gpus 2`: two self-launched ranks label their halves of the clip set, agree on
+    the slowest rank's time, all-gather the labels; rank 0's line names cfg3 and carries the same label checksum as a
+    one-rank run of the same job."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    lines = []
+    for extra in (["--gpus", "2", "--rehearse-on-one-gpu"], ["--gpus", "1"]):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--config", "cfg3", "--total-clips", "64", "--clips-per-pass",
+               "32", "--steps", "1", "--warmup", "1", "--no-kernel-timing"] + extra
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        assert len(out) == 1
+        lines.append(json.loads(out[0]))
+    two, one = lines
+    assert two["n_gpus"] == 2 and two["config"]["communicator_ranks"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["workload"].startswith("cfg3") and len(two["config"]["ms_per_step_per_rank"]) == 2
+    assert two["config"]["labels_sha256"] == one["config"]["labels_sha256"] and two["config"]["kept"] == one["config"]["kept"]
+    assert 0 < one["config"]["kept"] < 64
