@@ -180,12 +180,15 @@ KERNEL_SYMBOLS = {"gemm_nt": "gemm_kernel<1, 1, true", "gemm_nn": "gemm_kernel<1
                   "mha_fwd": "mha_fwd_pp_kernel", "mha_bwd": "mha_bwd_kernel<false>"}
 
 
+TRAFFIC_FILE = "r2_traffic.json"
+
+
 def measured_traffic(key):
     """HBM bytes per launch of the kernel class (launch-weighted over its instantiations), from the committed
-    counter passes over this same command (profiles/r2_traffic.json, written by tools/collect_traffic.sh); None if
+    counter passes over this same command (profiles/<TRAFFIC_FILE>, written by tools/collect_traffic.sh); None if
     no such measurement exists."""
     symbol = KERNEL_SYMBOLS.get(key.split(" ")[0])
-    path = os.path.join(ROOT, "profiles", "r2_traffic.json")
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if symbol is None or not os.path.exists(path):
         return None, symbol
     rows = [v for k, v in json.load(open(path))["kernels"].items() if k.startswith(symbol)]
@@ -437,6 +440,10 @@ def main():
             roofline = {"kernel": dom[0], "symbol": symbol, "bound": "mfma", "achieved": round(ach, 2),
                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                         "traffic": traffic,
+                        "traffic_source": (None if traffic is None else
+                                           "profiles/%s (committed rocprofv3 counter pass over this same command, "
+                                           "launch-weighted over the class's instantiations; not measured in this run)"
+                                           % TRAFFIC_FILE),
                         "launches": a["launches"], "avg_us": round(a["ms"] * 1e3 / a["launches"], 2),
                         "flops_per_launch": a["work"] / a["launches"]}
             if exclusive is not None:
