@@ -79,10 +79,12 @@ __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >
 
 // attention-probability dropout: keep(q, key) for (clip, head) stream key sbh; Lq, Lk <= 65536.
 // The fp32 matrix instruction does not overlap with vector ALU work on its SIMD, so every vector
-// instruction in the attention loops costs wall time: the per-element hash is built from full-rate
-// operations only (24-bit multiply-add, shifts, xors; two rounds), 10 instructions instead of the
-// 32-bit-multiply mixer's 11 of which two run at quarter rate.  Drop rate, neighbour correlations and
-// row/column count dispersion of the masks match the 32-bit mixer's.
+// instruction in the attention loops costs wall time: the hash is built from full-rate operations only
+// (24-bit multiply-add, shifts, xors; two rounds) and ONE hash serves the two keys 2j, 2j+1 of a query:
+// its low 16 bits decide the even key, its high 16 bits the odd one (keep iff half >= thr16, thr16 =
+// round-down of p * 65536).  In the forward kernels a lane holds both keys of a pair, so the hash work per
+// element halves; in the backward kernel (keys on the lanes) a lane shifts its half into place.  Drop rate,
+// neighbour correlations and row/column count dispersion of the masks match a 32-bit mixer's per-element draw.
 __device__ __forceinline__ unsigned attn_stream_key(unsigned seed, unsigned bh) { return spot_mix32(bh * 0x9E3779B1U ^ seed); }
 __device__ __forceinline__ unsigned attn_mix(unsigned x) {
     x ^= x >> 15;
@@ -92,17 +94,32 @@ __device__ __forceinline__ unsigned attn_mix(unsigned x) {
     x ^= x >> 13;
     return x;
 }
-__device__ __forceinline__ bool attn_keep(unsigned sbh, unsigned q, unsigned key, unsigned thr) {
-    return attn_mix(((q << 16) | key) ^ sbh) >= thr;
+__device__ __forceinline__ bool attn_keep(unsigned sbh, unsigned q, unsigned key, unsigned thr16) {
+    const unsigned bits = attn_mix(((q << 16) | (key & ~1u)) ^ sbh);
+    return ((key & 1u) ? bits >> 16 : bits & 0xffffu) >= thr16;
 }
+// 16-bit threshold of the pair hash from the library-wide 32-bit one (0 = dropout off; a rate below 2^-16 rounds up)
+static inline unsigned attn_threshold(float p) {
+    const unsigned t = spot_drop_threshold(p);
+    return t == 0 ? 0u : ((t >> 16) ? (t >> 16) : 1u);
+}
+
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 // Online-softmax step on one 32-key score block held as S^T (keys on the accumulator rows, the
 // lane's query fixed).  Scores arrive in the log2 domain (Q was pre-multiplied by scale*log2 e).
-// CHECK = false skips the bounds / key-padding tests (whole block valid).
-template <bool CHECK>
-__device__ __forceinline__ void softmax_block(f32x16& s, f32x16& o, float& m_run, float& l_run, int key0, int h, int Lk,
+// The reference value m_ref that the exponentials are taken against is NOT the exact running maximum:
+// it moves (and the running sums are rescaled) only when some query of the wave meets a score more than
+// LAZY_TAU above its reference, so that step is rare after the first blocks and the common path is
+// subtract, exp2, add.  Probabilities relative to the reference stay below 2^LAZY_TAU and the sums
+// below 2^(LAZY_TAU + 16): the normalised output and the log-sum-exp do not depend on the reference.
+// check = true (workgroup-uniform) applies the bounds / key-padding tests first.
+constexpr float LAZY_TAU = 8.f;
+__device__ __forceinline__ void softmax_block(bool check, f32x16& s, f32x16& o, float& m_ref, float& l_run, int key0, int h, int Lk,
                                               const unsigned char* mb, unsigned qs, unsigned drop_thr, float drop_scale) {
-    if (CHECK) {
+    if (check) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int key = key0 + acc_row(e, h);
@@ -115,27 +132,33 @@ __device__ __forceinline__ void softmax_block(f32x16& s, f32x16& o, float& m_run
     for (int e = 3; e < 15; e += 2) mx = fmaxf(fmaxf(mx, s[e]), s[e + 1]);
     mx = fmaxf(mx, s[15]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float m_use = m_new == -INFINITY ? 0.f : m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        s[e] = __builtin_amdgcn_exp2f(s[e] - m_use);
-        psum += s[e];
-    }
-    if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {      // the running maximum moved for some query of this wave
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run = -inf -> 0
+    if (__builtin_amdgcn_ballot_w64(mx > m_ref + LAZY_TAU)) {      // (-inf + tau = -inf: the first live block always enters)
+        const float m_new = fmaxf(m_ref, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_ref - (m_new == -INFINITY ? 0.f : m_new));   // m_ref = -inf -> 0
         l_run *= alpha;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[e] *= alpha;
-        m_run = m_new;
+        o *= alpha;
+        m_ref = m_new;
     }
-    l_run += psum;
-    if (drop_thr) {   // dropout acts on the normalised probabilities: the row sum above stays undropped
-        const unsigned x0 = qs ^ (unsigned)(key0 + 4 * h);   // low 16 bits: key; acc_row(e,h) = r(e) + 4h with r(e) & 4 == 0
+    const float m_use = m_ref == -INFINITY ? 0.f : m_ref;
+    s = s - m_use;                                  // packed subtracts
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-            s[e] = attn_mix(x0 ^ (unsigned)acc_row(e, 0)) >= drop_thr ? s[e] * drop_scale : 0.f;
+    for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e]);
+    {                                               // row sum as a tree of packed adds
+        const f32x8 a8 = s.lo + s.hi;
+        const f32x4v a4 = a8.lo + a8.hi;
+        const f32x2v a2 = a4.lo + a4.hi;
+        l_run += a2.x + a2.y;
+    }
+    if (drop_thr) {   // dropout acts on the normalised probabilities: the row sum above stays undropped
+        // keys of accumulator elements (e, e + 1), e even: key0 + 4h + r, r = acc_row(e, 0) even, and r + 1
+        const unsigned x0 = qs ^ (unsigned)(key0 + 4 * h);   // low 16 bits: key
+        s = s * drop_scale;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const unsigned bits = attn_mix(x0 ^ (unsigned)acc_row(e, 0));
+            s[e] = (bits & 0xffffu) >= drop_thr ? s[e] : 0.f;
+            s[e + 1] = (bits >> 16) >= drop_thr ? s[e + 1] : 0.f;
+        }
     }
 }
 
@@ -221,8 +244,7 @@ __global__ __launch_bounds__(256, 3) void mha_fwd_kernel(
                 mma(kf, qf, s);
             }
             // ---- mask, online softmax (per lane = per query)
-            if (mb || key0 + 32 > Lk) softmax_block<true>(s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
-            else softmax_block<false>(s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
+            softmax_block(mb || key0 + 32 > Lk, s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
             // ---- O^T += V^T P^T   (reduction slot e of half h is key acc_row(e,h): the S^T accumulator IS the operand)
             {
                 Frag<BF16> vf, pf;
@@ -335,8 +357,7 @@ __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
     };
     auto softmax = [&](int j, f32x16& s) {
         const int key0 = j * 32;
-        if (mb || key0 + 32 > Lk) softmax_block<true>(s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
-        else softmax_block<false>(s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
+        softmax_block(mb || key0 + 32 > Lk, s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
     };
 
     fetch(0);
@@ -397,7 +418,7 @@ static int mha_fwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
     SPOT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mha_fwd: drop_p=%f outside [0,1)", drop_p);
     SPOT_CHECK_ARG(drop_p == 0.f || (Lq <= 65536 && Lk <= 65536), "mha_fwd: dropout needs Lq, Lk <= 65536");
     if (B == 0) return SPOT_OK;
-    const unsigned thr = spot_drop_threshold(drop_p);
+    const unsigned thr = attn_threshold(drop_p);
     const float dscale = 1.f / (1.f - drop_p);
     if (bf16) {
         // the matrix work shrinks 16-fold: the loop is vector-bound and gains nothing from pairing matrix with vector phases
@@ -495,7 +516,8 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const int key_w0 = blockIdx.x * 128 + wave * 32;
     const int key = key_w0 + l31;
     const float c = scale * 1.4426950408889634f;   // folded into the K fragment: scores come out in the log2 domain
-    const unsigned ks = attn_stream_key(drop_seed, (unsigned)(b * H + head)) ^ (unsigned)key;
+    const unsigned ks = attn_stream_key(drop_seed, (unsigned)(b * H + head)) ^ (unsigned)(key & ~1);
+    const unsigned half_shift = (key & 1) ? 0u : 16u, thr_hi = drop_thr << 16;
 
     const float* Qb = Q + (long)b * Lq * ldq + head * DH;
     const float* Gb = dO + (long)b * Lq * lddo + head * DH;
@@ -604,7 +626,9 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
             const unsigned x0 = ks ^ ((unsigned)(t * 32 + 4 * h) << 16);     // query index sits in the high half
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float ms = attn_mix(x0 ^ ((unsigned)acc_row(e, 0) << 16)) >= drop_thr ? drop_scale : 0.f;
+                // the pair hash of (query, key & ~1): an odd key reads its high half; an even key's low half is moved up,
+                // and the comparison runs on the upper 16 bits (the threshold's lower 16 are zero)
+                const float ms = (attn_mix(x0 ^ ((unsigned)acc_row(e, 0) << 16)) << half_shift) >= thr_hi ? drop_scale : 0.f;
                 const float p = s[e];
                 s[e] = p * ms;                              // dropped probabilities feed dV
                 dp[e] = p * (dp[e] * ms - dl[e]);           // dS = P (M dP_drop - delta)
@@ -696,11 +720,11 @@ static int mha_bwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
     if (bf16)
         mha_bwd_kernel<true><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, d_out, lddo, lse, delta_ws, key_padding_mask,
                                                        dq, lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale,
-                                                       spot_drop_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
+                                                       attn_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
     else
         mha_bwd_kernel<false><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, d_out, lddo, lse, delta_ws, key_padding_mask,
                                                         dq, lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale,
-                                                        spot_drop_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
+                                                        attn_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
     SPOT_CHECK_LAUNCH("mha_bwd");
     return SPOT_OK;
 }
@@ -743,7 +767,7 @@ extern "C" int spot_mha_dropout_mask(unsigned char* mask, int B, int nhead, int 
                                      unsigned drop_seed, hipStream_t stream) {
     SPOT_CHECK_ARG(mask && B > 0 && nhead > 0 && Lq > 0 && Lk > 0 && Lq <= 65536 && Lk <= 65536, "mha_dropout_mask: bad arguments");
     SPOT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mha_dropout_mask: drop_p=%f outside [0,1)", drop_p);
-    attn_mask_kernel<<<2048, 256, 0, stream>>>(mask, Lq, Lk, B * nhead, spot_drop_threshold(drop_p), drop_seed);
+    attn_mask_kernel<<<2048, 256, 0, stream>>>(mask, Lq, Lk, B * nhead, attn_threshold(drop_p), drop_seed);
     SPOT_CHECK_LAUNCH("mha_dropout_mask");
     return SPOT_OK;
 }

@@ -16,7 +16,7 @@ constexpr int BK = 32, KPAD = BK + 4;
 
 struct Args {
     const float* A; const float* B; float* C; const float* bias; const float* res;
-    int M, N, K, prio_div;
+    int M, N, K, prio_div; long long* clk = nullptr;
 };
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -208,7 +208,7 @@ static void run_all(std::vector<Variant>& vs, double gflop, int rounds = 7) {
     for (auto& v : vs) {
         std::sort(v.t.begin(), v.t.end());
         const double mn = v.t.front(), md = v.t[v.t.size() / 2];
-        printf("   %-46s min %8.1f us %6.1f TF | median %8.1f us %6.1f TF\n", v.tag.c_str(), mn, gflop / mn * 1e-3, md, gflop / md * 1e-3);
+        printf("   %-46s min %8.1f us %6.1f TF | median %8.1f us %6.1f TF\n", v.tag.c_str(), mn, gflop / mn * 1e3, md, gflop / md * 1e3);
     }
 }
 
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void loop_probe(Args g) {
     float keep = 0.f;
     const int nkt = g.K / BK;
     int fk = 0;
+    const long long c0 = clock64(), w0 = wall_clock64();
     float4 ra = make_float4(1e-3f * lane, 2e-3f, 3e-3f, 4e-3f), rb = make_float4(1.f, 0.5f, 0.25f, 0.125f);
     for (int kt = 0; kt < nkt; ++kt) {
         if (PART >= 3) {
@@ -313,6 +314,11 @@ __global__ __launch_bounds__(256, TS == 2 ? 3 : 6) void loop_probe(Args g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) sum += acc[t][u][e];
     if (sum == 12345.678f) g.C[0] = 1.f;
+    if (g.clk && tid == 0 && (blockIdx.x & 255) == 17) {
+        const long long c1 = clock64(), w1 = wall_clock64();
+        g.clk[2 * (blockIdx.x >> 8)] = c1 - c0;
+        g.clk[2 * (blockIdx.x >> 8) + 1] = w1 - w0;
+    }
 }
 
 template <int TS, int PART>
@@ -529,6 +535,30 @@ int main(int argc, char** argv) {
         add("v2 128x128 S=2 k loop only", [&] { return run_v2<2, 2, 2>(a); });
         add("v2 128x128 S=2 bias+relu", [&] { return run_v2<2, 2, 4>(a); });
         add("v2 128x128 S=2 bias+relu prio/32", [&] { a.prio_div = 32; return run_v2<2, 2, 4, 1>(a); });
+        if (argc > 1) {
+            vs.clear();
+            long long* clk; CK(hipMalloc(&clk, 4096 * 16)); 
+            auto freq = [&](const char* tag, std::function<double()> f) {
+                CK(hipMemset(clk, 0, 4096 * 16)); a.clk = clk; f(); CK(hipDeviceSynchronize()); a.clk = nullptr;
+                std::vector<long long> h(8192); CK(hipMemcpy(h.data(), clk, 4096 * 16, hipMemcpyDeviceToHost));
+                double cs = 0, ws = 0; int n = 0;
+                for (int i = 0; i < 4096; ++i) if (h[2 * i + 1] > 0) { cs += h[2 * i]; ws += h[2 * i + 1]; ++n; }
+                printf("   clock %-30s %d samples: shader cycles / 100 MHz ticks = %.3f (-> %.0f MHz), mean wg life %.1f us\n", tag, n, cs / ws, cs / ws * 100.0, ws / n / 100.0);
+            };
+            freq("64 part0", [&] { return run_probe<1, 0>(a); });
+            freq("64 part1", [&] { return run_probe<1, 1>(a); });
+            freq("64 part3", [&] { return run_probe<1, 3>(a); });
+            freq("128 part0", [&] { return run_probe<2, 0>(a); });
+            freq("128 part3", [&] { return run_probe<2, 3>(a); });
+            add("probe 64  part0 mfma only", [&] { return run_probe<1, 0>(a); });
+            add("probe 64  part1 +lds reads", [&] { return run_probe<1, 1>(a); });
+            add("probe 64  part2 +barriers", [&] { return run_probe<1, 2>(a); });
+            add("probe 64  part3 +global loads", [&] { return run_probe<1, 3>(a); });
+            add("probe 128 part0 mfma only", [&] { return run_probe<2, 0>(a); });
+            add("probe 128 part1 +lds reads", [&] { return run_probe<2, 1>(a); });
+            add("probe 128 part2 +barriers", [&] { return run_probe<2, 2>(a); });
+            add("probe 128 part3 +global loads", [&] { return run_probe<2, 3>(a); });
+        }
         run_all(vs, gf);
         CK(hipFree((void*)a.A)); CK(hipFree((void*)a.B)); CK(hipFree((void*)a.bias)); CK(hipFree((void*)a.res)); CK(hipFree(C));
     }
