@@ -495,7 +495,8 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(const float* __restrict_
     }
 }
 
-template <bool BF16>
+// DROP: attention dropout active (drop_thr != 0); a template parameter so that the no-dropout loop carries none of it
+template <bool BF16, bool DROP>
 __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
     const float* __restrict__ dO, long lddo, const float* __restrict__ LSE, const float* __restrict__ delta,
@@ -550,10 +551,10 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
         }
         if (tid < 32) {
             const int qq = t * 32 + tid;
-            sl = qq < Lq ? Lb[qq] * 1.4426950408889634f : INFINITY;
+            sl = qq < Lq ? -(Lb[qq] * 1.4426950408889634f) : -INFINITY;      // the score accumulator starts at -LSE
         } else if (tid < 64) {
             const int qq = t * 32 + tid - 32;
-            sl = qq < Lq ? Db[qq] : 0.f;
+            sl = qq < Lq ? (DROP ? Db[qq] : -Db[qq]) : 0.f;                  // without dropout dP starts at -delta
         }
     };
     auto stash = [&](int buf) {
@@ -602,11 +603,11 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
         for (int g4 = 0; g4 < 4; ++g4) {
             const float4 l4 = *reinterpret_cast<const float4*>(Ls(cur) + 8 * g4 + 4 * h);
             const float4 d4 = *reinterpret_cast<const float4*>(Ds(cur) + 8 * g4 + 4 * h);
-            s[4 * g4] = -l4.x; s[4 * g4 + 1] = -l4.y; s[4 * g4 + 2] = -l4.z; s[4 * g4 + 3] = -l4.w;
+            s[4 * g4] = l4.x; s[4 * g4 + 1] = l4.y; s[4 * g4 + 2] = l4.z; s[4 * g4 + 3] = l4.w;
             dl[4 * g4] = d4.x; dl[4 * g4 + 1] = d4.y; dl[4 * g4 + 2] = d4.z; dl[4 * g4 + 3] = d4.w;
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dp[e] = drop_thr ? 0.f : -dl[e];
+        for (int e = 0; e < 16; ++e) dp[e] = DROP ? 0.f : dl[e];
         {
             Frag<BF16> qf, gf;
             load_frag(qf, qs + l31 * QP + 16 * h);
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e] = kdead ? 0.f : s[e];
         }
-        if (drop_thr) {
+        if (DROP) {
             const unsigned x0 = ks ^ ((unsigned)(t * 32 + 4 * h) << 16);     // query index sits in the high half
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -717,14 +718,19 @@ static int mha_bwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
                                                                           nhead, total);
     SPOT_CHECK_LAUNCH("mha_bwd(delta)");
     dim3 grid((Lk + 127) / 128, nhead, B);
-    if (bf16)
-        mha_bwd_kernel<true><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, d_out, lddo, lse, delta_ws, key_padding_mask,
-                                                       dq, lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale,
-                                                       attn_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
-    else
-        mha_bwd_kernel<false><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, d_out, lddo, lse, delta_ws, key_padding_mask,
-                                                        dq, lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale,
-                                                        attn_threshold(drop_p), drop_seed, 1.f / (1.f - drop_p));
+    const unsigned thr = attn_threshold(drop_p);
+#define SPOT_MHA_BWD(BF, DR)                                                                                                   \
+    mha_bwd_kernel<BF, DR><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, d_out, lddo, lse, delta_ws, key_padding_mask, dq, \
+                                                     lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale, thr, drop_seed,           \
+                                                     1.f / (1.f - drop_p))
+    if (bf16) {
+        if (thr) SPOT_MHA_BWD(true, true);
+        else SPOT_MHA_BWD(true, false);
+    } else {
+        if (thr) SPOT_MHA_BWD(false, true);
+        else SPOT_MHA_BWD(false, false);
+    }
+#undef SPOT_MHA_BWD
     SPOT_CHECK_LAUNCH("mha_bwd");
     return SPOT_OK;
 }

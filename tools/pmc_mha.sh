@@ -25,11 +25,12 @@ for d in ("pmc1","pmc2"):
 for k,v in tot.items():
     print(k)
     for c,(x,nl) in sorted(v.items()): print("   %-30s %.5g   [%.5g per launch, %d launches]"%(c,x,x/nl,nl))
-    if "SQ_INSTS_VALU" in v and "SQ_INSTS_MFMA" in v:
+    if "SQ_INSTS_VALU" in v and v.get("SQ_INSTS_MFMA", (0, 0))[0] > 0:
         valu, mfma = v["SQ_INSTS_VALU"][0], v["SQ_INSTS_MFMA"][0]
         print("   vector-ALU instructions that are not matrix instructions per matrix instruction: %.3f" % ((valu - mfma) / mfma))
 PY
 cd /tmp
+cp $(ls $R/gpurun_out/pmc2/*/*counter_collection.csv | head -1) $R/gpurun_out/pmc2_last.csv
 rm -rf $R/gpurun_out/pmc1 $R/gpurun_out/pmc2
 done
 cat $OUT
