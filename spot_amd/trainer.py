@@ -60,7 +60,11 @@ class LTRSparseTrainer:
         # before the forward pass
         self._buffers = [t for _, t in self.arena.f32 if not isinstance(t, torch.nn.Parameter)]
         self._buffers += [t for _, t in self.arena.i64]
-        self._buffers_before = [torch.empty_like(t) for t in self._buffers]
+        # Snapshot = the two flat allocations whole (one copy each instead of one per buffer: ~130 launches less on the
+        # critical stream).  Parameters do not change between the snapshot and the skip decision, so putting the whole
+        # allocation back restores exactly the buffers.
+        self._flat_before = torch.empty_like(self.arena.flat) if self._buffers else None
+        self._i64_before = torch.empty_like(self.arena.flat_i64) if self._buffers else None
         self.num_frames = 0
         self.skipped = 0
         self._prefetched = None
@@ -152,8 +156,14 @@ class LTRSparseTrainer:
         if training:
             self.arena.zero_grad()      # before the forward pass: also resets the kernels' gradient bookkeeping
             if self._buffers:
-                torch._foreach_copy_(self._buffers_before, self._buffers)
+                self._flat_before.copy_(self.arena.flat)
+                self._i64_before.copy_(self.arena.flat_i64)
         loss, stats, n_keep = self._sparse_training(data_sup, data_unsup, aug_label, training)
+        if training:
+            # The next iteration's teacher pass goes out before the host waits for this iteration's flags: the device
+            # then has work queued across the read, and the pass runs beside the tail of the forward and the backward.
+            # A skipped iteration leaves the teacher as it was, so the labels stay valid either way.
+            self._prefetch_pseudo_labels(i + 1, next_unsup)
         # single host read: kept count and loss finiteness
         flags = torch.stack([n_keep.float().reshape(()), torch.isfinite(loss.detach()).float().reshape(())]).tolist()
         kept, finite = all_ranks_all([flags[0] > 0, flags[1] > 0], self.device)
@@ -161,7 +171,8 @@ class LTRSparseTrainer:
             # no valid pseudo label on some rank: the reference skips before the student forward, so nothing of
             # that forward may persist (a non-finite loss, below, is noticed after the forward there too)
             if training and self._buffers:
-                torch._foreach_copy_(self._buffers, self._buffers_before)
+                self.arena.flat.copy_(self._flat_before)
+                self.arena.flat_i64.copy_(self._i64_before)
             self.skipped += 1
             return None
         if not finite:
@@ -169,7 +180,6 @@ class LTRSparseTrainer:
             return None
         if training:
             self.reducer.arm()
-            self._prefetch_pseudo_labels(i + 1, next_unsup)
             loss.backward()
             self.reducer.finish()
             if self.clip_grad_norm:
