@@ -35,8 +35,13 @@ class BaseSparseActor:
         self.teacher_net.to(device)
 
     def train(self, mode=True):
-        self.student_net.train(mode)
-        if self.objective is not None:
+        # The trainer flips the mode around every network pass; walking the module tree costs half a millisecond of
+        # host time each, at points where the device waits for the next launch.  The walk is skipped when the root
+        # already has the mode (nothing in this package sets the mode of a sub-module alone).
+        mode = bool(mode)
+        if self.student_net.training != mode:
+            self.student_net.train(mode)
+        if self.objective is not None and self.objective.training != mode:
             self.objective.train(mode)
 
     def eval(self):

@@ -166,5 +166,6 @@ def check(rc, what=""):
 
 def call(name, *args):
     """Call a C-ABI entry point and raise on a non-zero status."""
-    rc = getattr(load(), name)(*args)
-    check(rc, name)
+    rc = getattr(_lib or load(), name)(*args)
+    if rc != 0:
+        check(rc, name)

@@ -14,7 +14,15 @@ from . import lib
 from .lib import GemmDesc
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_current_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _st():
+    """The current HIP stream of the current device as a C pointer.  Asked for once per kernel launch, so it takes the
+    framework's raw-handle query (a fraction of a microsecond) where that exists instead of building a Stream object."""
+    if _raw_stream is not None and _current_device is not None:
+        return C.c_void_p(_raw_stream(_current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -608,15 +616,22 @@ def linear_dgrad(dy2, W, mask=None, out=None, accumulate=False, residual=None, a
     return out
 
 
-_SPLITK_TARGET = 512
-
-
 def _splitk_for(rows_out, cols_out, k):
-    tiles = ((rows_out + 127) // 128) * ((cols_out + 127) // 128)
-    want = max(1, _SPLITK_TARGET // tiles)
+    """K ranges of a weight-gradient product (its reduction runs over the token rows of the batch).
+
+    Measured on MI355X (tools/probes/splitk_scan.py): the launch is fastest when the 64x64 output tiles times the
+    ranges make about four workgroups per CU in whole multiples of the 256 CUs (a ragged last round leaves CUs with
+    one workgroup more than their neighbours, and they set the time), and when a range still holds twenty k tiles
+    (the atomic adds of a range's 64x64 partial tile cost as much as ten k tiles of products)."""
+    t64 = ((rows_out + 63) // 64) * ((cols_out + 63) // 64)
+    nkt = max(1, k // 32)
+    sk = min(max(1, 1024 // t64), max(1, nkt // 20))
+    step = 256 // math.gcd(t64, 256)
+    if sk >= step:
+        sk -= sk % step
     # never 1: with two or more ranges the kernel adds into the gradient with atomics, which is what makes it safe
     # for the template and the search pass to deliver a shared weight's gradient from two streams at once
-    return max(2, min(want, k // 256 if k >= 256 else 1))
+    return max(2, sk)
 
 
 def linear_wgrad(dy2, x2, out=None, accumulate=False, bias_out=None):

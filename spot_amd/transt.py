@@ -88,7 +88,7 @@ class InputProjFn(torch.autograd.Function):
             sk = ops._sink(pw)
             dw = sk.view(Cout, Cin) if sk is not None else torch.zeros_like(w2)
             ops.gemm(dtok, feat, dw, Cout, Cin, B * HW, transA=True, lda=Cout, ldb=HW, ldc=Cin, kseg=HW,
-                     segA=HW * Cout, segB=Cin * HW, splitk=max(2, min(B * HW // 256, 32)), accumulate=True)
+                     segA=HW * Cout, segB=Cin * HW, splitk=ops._splitk_for(Cout, Cin, B * HW), accumulate=True)
             dw = None if sk is not None else dw.view_as(weight)
         if ctx.needs_input_grad[2]:
             sk = ops._sink(pb)
