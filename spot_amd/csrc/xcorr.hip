@@ -898,7 +898,17 @@ __global__ __launch_bounds__(256) void groupdw_bwd_kernel(Branch b0, Branch b1, 
 constexpr int RD = 9;       // dx rows per work item
 constexpr int TAPS = 32;    // tap slots of the reduction (25 used at most)
 
-// v[0..32) per lane -> lane l holds the 64-lane total of slot 16 b0 + 8 b1 + 4 b2 + 2 b3 + b4 (b_s = bit s of l)
+// value of lane (l ^ 1) / (l ^ 2): data-parallel-primitive moves inside the quad (vector ALU; the general lane
+// exchange goes through the LDS crossbar, which is this kernel's busiest unit)
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+}
+
+// v[0..32) per lane -> lane l holds the 64-lane total of slot 16 b0 + 8 b1 + 4 b2 + 2 b3 + b4 (b_s = bit s of l).
+// The first two steps (24 of the 31 exchanges) stay inside the quad.
 __device__ __forceinline__ float reduce_slots(float (&v)[TAPS], int lane) {
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
@@ -912,7 +922,7 @@ __device__ __forceinline__ float reduce_slots(float (&v)[TAPS], int lane) {
             asm volatile("" : "+v"(lo_v), "+v"(hi_v));
             const float keep = hi ? hi_v : lo_v;
             const float send = hi ? lo_v : hi_v;
-            v[i] = keep + __shfl_xor(send, 1 << s);
+            v[i] = keep + (s == 0 ? quad_xor1(send) : (s == 1 ? quad_xor2(send) : __shfl_xor(send, 1 << s)));
         }
     }
     return v[0] + __shfl_xor(v[0], 32);

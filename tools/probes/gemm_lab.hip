@@ -408,6 +408,28 @@ __global__ __launch_bounds__(256) void gemm_v2(Args g) {
         if (kt + S - 1 < nkt) issue(kt + S - 1, slot == 0 ? S - 1 : slot - 1);
         const float* As = lds + slot * STAGE_F;
         const float* Bs = As + A_F;
+        if (PRIO == 2) {          // all four k groups' fragments requested up front: the matrix instructions of group g run
+                                  // while the reads of the later groups are still in flight
+            float4 a[4][TS], b[4][TS];
+#pragma unroll
+            for (int gk = 0; gk < 4; ++gk) {
+#pragma unroll
+                for (int t = 0; t < TS; ++t) a[gk][t] = *reinterpret_cast<const float4*>(As + (wm * WT + t * 32) * 32 + fo[gk]);
+#pragma unroll
+                for (int u = 0; u < TS; ++u) b[gk][u] = *reinterpret_cast<const float4*>(Bs + (wn * WT + u * 32) * 32 + fo[gk]);
+            }
+#pragma unroll
+            for (int gk = 0; gk < 4; ++gk)
+#pragma unroll
+                for (int t = 0; t < TS; ++t)
+#pragma unroll
+                    for (int u = 0; u < TS; ++u) {
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gk][t].x, b[gk][u].x, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gk][t].y, b[gk][u].y, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gk][t].z, b[gk][u].z, acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gk][t].w, b[gk][u].w, acc[t][u], 0, 0, 0);
+                    }
+        } else {
 #pragma unroll
         for (int gk = 0; gk < 4; ++gk) {
             float4 a[TS], b[TS];
@@ -424,6 +446,7 @@ __global__ __launch_bounds__(256) void gemm_v2(Args g) {
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
                 }
+        }
         }
         slot = slot + 1 == S ? 0 : slot + 1;
     }
@@ -530,6 +553,9 @@ int main(int argc, char** argv) {
         add("v2 64x64   S=2", [&] { return run_v2<1, 2, 0>(a); });
         add("v2 64x64   S=2 k loop only", [&] { return run_v2<1, 2, 2>(a); });
         add("v2 64x64   S=2 bias+relu", [&] { return run_v2<1, 2, 4>(a); });
+        add("v2 64x64   S=2 full, reads up front", [&] { return run_v2<1, 2, 0, 2>(a); });
+        add("v2 64x64   S=2 bias+relu, reads up front", [&] { return run_v2<1, 2, 4, 2>(a); });
+        add("v2 64x64   S=2 k loop only, reads up front", [&] { return run_v2<1, 2, 2, 2>(a); });
         add("v2 64x64   S=2 prio/32", [&] { a.prio_div = 32; return run_v2<1, 2, 0, 1>(a); });
         add("v2 128x128 S=2", [&] { return run_v2<2, 2, 0>(a); });
         add("v2 128x128 S=2 k loop only", [&] { return run_v2<2, 2, 2>(a); });
