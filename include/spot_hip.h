@@ -220,6 +220,11 @@ typedef struct spot_gemm_desc {
 } spot_gemm_desc;
 
 int spot_gemm_f32(const spot_gemm_desc* desc /* host */, hipStream_t stream);
+/* Two independent problems.  One launch when both ask for tile = 32 with the same transA / transB and batch = 1 (one clip:
+ * FeatureFusionLayer.forward_post runs the same products on the template and on the search stream with different weights,
+ * transt_fusion.py:204-244, and such launches last as long as their latencies); otherwise the two calls one after the
+ * other.  The arithmetic of either problem is that of spot_gemm_f32. */
+int spot_gemm_pair_f32(const spot_gemm_desc* desc0 /* host */, const spot_gemm_desc* desc1 /* host */, hipStream_t stream);
 
 /* Bias-free 3x3 convolution, stride 1, dilation d = 1 or 2 with padding d, NCHW fp32 (conv2 of the ResNet
  * bottlenecks that do not stride: ltr/models/backbone/resnet.py:79-81; d = 2 in layer3's first block, :166), by
@@ -356,6 +361,13 @@ long spot_mha_fwd_splitk_ws_floats(int B, int Lq, int nhead, int nsplit);
 int spot_mha_fwd_splitk_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* out,
                             long ldo, const unsigned char* key_padding_mask, float* ws, int nsplit, int B, int Lq, int Lk,
                             int nhead, int head_dim, float scale, hipStream_t stream);
+/* Two such calls of one clip each (B = 1) in two launches instead of four: the attention blocks of a fusion layer's
+ * template and search streams (transt_fusion.py:212-230).  ws0 / ws1: spot_mha_fwd_splitk_ws_floats(1, Lq, nhead, nsplit). */
+int spot_mha_fwd_splitk_pair_f32(const float* q0, long ldq0, const float* k0, long ldk0, const float* v0, long ldv0,
+                                 float* out0, long ldo0, const unsigned char* key_padding_mask0, float* ws0, int nsplit0,
+                                 int Lq0, int Lk0, const float* q1, long ldq1, const float* k1, long ldk1, const float* v1,
+                                 long ldv1, float* out1, long ldo1, const unsigned char* key_padding_mask1, float* ws1,
+                                 int nsplit1, int Lq1, int Lk1, int nhead, int head_dim, float scale, hipStream_t stream);
 
 /* spot_mha_fwd_splitk_f32 without the workspace argument, for callers that cannot allocate device memory: a frame
  * replayed under HIP graph capture, a serving loop or a harness that forbids hipMalloc.  It has no counterpart in the
@@ -400,6 +412,11 @@ int spot_mha_dropout_mask(unsigned char* mask, int B, int nhead, int Lq, int Lk,
  * x,y [rows,C]; mean,rstd [rows] (NULL to skip).  C multiple of 4, <= 1024. */
 int spot_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                            float* rstd, long rows, int C, float eps, hipStream_t stream);
+/* Two tensors of the same width in one launch, inference (no statistics kept): norm1x / norm2x of a fusion layer's two
+ * streams (transt_fusion.py:214-244). */
+int spot_layernorm_fwd_pair_f32(const float* x0, const float* gamma0, const float* beta0, float* y0, long rows0, float eps0,
+                                const float* x1, const float* gamma1, const float* beta1, float* y1, long rows1, float eps1,
+                                int C, hipStream_t stream);
 /* dx, dgamma, dbeta (the latter two overwritten, or added to when accumulate != 0; either may be NULL).  ws: workspace of
  * spot_layernorm_bwd_ws_floats(rows, C) floats holding per-workgroup partial sums. */
 long spot_layernorm_bwd_ws_floats(long rows, int C);

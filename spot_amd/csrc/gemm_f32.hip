@@ -803,16 +803,16 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------
 constexpr int KS_TM = 32, KS_K = 128, KS_KP = KS_K + 4, KS_MP = KS_TM + 4, KS_TILE_F = KS_K * KS_MP;   // 4608 >= 32 * 132
 
+// (bid, zb): the workgroup's tile index and batch index (a kernel launched for two problems hands each workgroup
+//  the problem it belongs to and its index inside that problem)
 template <int LA, int LB>
-__global__ __launch_bounds__(256, 2) void gemm_ks4_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_ks4_body(const GemmArgs& g, int bid, int zb, float* lds) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) float lds[2 * KS_TILE_F];
     float* const As = lds;
     float* const Bs = lds + KS_TILE_F;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int ntn = g.N / KS_TM;
-    const int m0 = (blockIdx.x / ntn) * KS_TM, n0 = (blockIdx.x % ntn) * KS_TM;
-    const int zb = blockIdx.z;
+    const int m0 = (bid / ntn) * KS_TM, n0 = (bid % ntn) * KS_TM;
     const float* A = g.A + zb * g.strideA;
     const float* B = g.B + zb * g.strideB;
 
@@ -921,6 +921,22 @@ __global__ __launch_bounds__(256, 2) void gemm_ks4_kernel(GemmArgs g) {
     *reinterpret_cast<float4*>(cp) = v;
 }
 
+template <int LA, int LB>
+__global__ __launch_bounds__(256, 2) void gemm_ks4_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * KS_TILE_F];
+    gemm_ks4_body<LA, LB>(g, blockIdx.x, blockIdx.z, lds);
+}
+
+// Two independent problems of the same operand layouts in one launch (the template and the search stream of a fusion
+// layer run the same sequence of small products on different weights: one clip's launches last as long as their
+// latencies, so two side by side cost what one costs).  Workgroups 0 .. n0-1 belong to the first problem.
+template <int LA, int LB>
+__global__ __launch_bounds__(256, 2) void gemm_ks4_pair_kernel(GemmArgs g0, GemmArgs g1, int n0) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * KS_TILE_F];
+    if ((int)blockIdx.x < n0) gemm_ks4_body<LA, LB>(g0, blockIdx.x, 0, lds);
+    else gemm_ks4_body<LA, LB>(g1, (int)blockIdx.x - n0, 0, lds);
+}
+
 // Workgroup tile for a problem.  Measured on MI355X the two tiles reach the same rate per FLOP (the 64x64 one
 // keeps six workgroups per CU in flight against three), so the choice is about quantisation: MFMA work is handed
 // out in workgroups, the last round of a grid leaves CUs idle, and a 64x64 workgroup is a quarter of the work.
@@ -1000,13 +1016,14 @@ int launch(const GemmArgs& a, int batch, int tile, bool aligned, hipStream_t str
 
 }  // namespace
 
-extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
+// Checks a descriptor and fills the kernel arguments.  Returns SPOT_OK with a.M == 0 || a.N == 0 for an empty problem.
+static int gemm_prepare(const spot_gemm_desc* d, GemmArgs& a, int& ta, int& tb, bool& aligned) {
     SPOT_CHECK_ARG(d, "gemm: null descriptor");
     SPOT_CHECK_ARG(d->A && d->B && d->C, "gemm: null operand");
     SPOT_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0 && d->batch >= 1, "gemm: bad shape M=%d N=%d K=%d batch=%d",
                    d->M, d->N, d->K, d->batch);
+    a.M = d->M; a.N = d->N;
     if (d->M == 0 || d->N == 0) return SPOT_OK;
-    GemmArgs a;
     a.A = d->A; a.B = d->B; a.C = d->C;
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
@@ -1039,10 +1056,10 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
                        "gemm: split-K cannot be combined with relu/mask/dropout/BatchNorm epilogues");
         SPOT_CHECK_ARG(a.accumulate, "gemm: split-K accumulates atomically into C; zero C and set accumulate=1");
     }
-    const int ta = d->transA ? 0 : 1, tb = d->transB ? 0 : 1;   // template arg 1 = k-contiguous
+    ta = d->transA ? 0 : 1, tb = d->transB ? 0 : 1;   // template arg 1 = k-contiguous
     // 16-byte vector loads need aligned bases/strides and a contiguous extent that is a multiple of 4
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    bool aligned = al(a.A) && al(a.B) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && (a.strideA % 4 == 0) &&
+    aligned = al(a.A) && al(a.B) && (a.lda % 4 == 0) && (a.ldb % 4 == 0) && (a.strideA % 4 == 0) &&
                    (a.strideB % 4 == 0) && (a.segA % 4 == 0) && (a.segB % 4 == 0);
     aligned = aligned && (ta ? (a.K % 4 == 0 && a.kseg % 4 == 0) : (a.M % 4 == 0));
     aligned = aligned && (tb ? (a.K % 4 == 0 && a.kseg % 4 == 0) : (a.N % 4 == 0));
@@ -1068,10 +1085,43 @@ extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
                        "gemm: bf16x3 products need 16-byte aligned operands, K (and every K segment) a multiple of 32, "
                        "M and N multiples of 128 and no row sums (M=%d N=%d K=%d)", a.M, a.N, a.K);
     }
+    return SPOT_OK;
+}
+
+extern "C" int spot_gemm_f32(const spot_gemm_desc* d, hipStream_t stream) {
+    GemmArgs a;
+    int ta, tb;
+    bool aligned;
+    const int rc = gemm_prepare(d, a, ta, tb, aligned);
+    if (rc != SPOT_OK || a.M == 0 || a.N == 0) return rc;
     if (ta && tb) launch<1, 1>(a, d->batch, d->tile, aligned, stream);
     else if (ta && !tb) launch<1, 0>(a, d->batch, d->tile, aligned, stream);
     else if (!ta && tb) launch<0, 1>(a, d->batch, d->tile, aligned, stream);
     else launch<0, 0>(a, d->batch, d->tile, aligned, stream);
     SPOT_CHECK_LAUNCH("gemm");
+    return SPOT_OK;
+}
+
+extern "C" int spot_gemm_pair_f32(const spot_gemm_desc* d0, const spot_gemm_desc* d1, hipStream_t stream) {
+    SPOT_CHECK_ARG(d0 && d1, "gemm_pair: null descriptor");
+    GemmArgs a0, a1;
+    int ta0, tb0, ta1, tb1;
+    bool al0, al1;
+    int rc = gemm_prepare(d0, a0, ta0, tb0, al0);
+    if (rc != SPOT_OK) return rc;
+    rc = gemm_prepare(d1, a1, ta1, tb1, al1);
+    if (rc != SPOT_OK) return rc;
+    const bool one_launch = d0->tile == 32 && d1->tile == 32 && d0->batch == 1 && d1->batch == 1 && ta0 == ta1 && tb0 == tb1 &&
+                            a0.M > 0 && a0.N > 0 && a1.M > 0 && a1.N > 0;
+    if (!one_launch) {
+        rc = spot_gemm_f32(d0, stream);
+        return rc != SPOT_OK ? rc : spot_gemm_f32(d1, stream);
+    }
+    const int n0 = (a0.M / KS_TM) * (a0.N / KS_TM), n1 = (a1.M / KS_TM) * (a1.N / KS_TM);
+    if (ta0 && tb0) gemm_ks4_pair_kernel<1, 1><<<n0 + n1, 256, 0, stream>>>(a0, a1, n0);
+    else if (ta0 && !tb0) gemm_ks4_pair_kernel<1, 0><<<n0 + n1, 256, 0, stream>>>(a0, a1, n0);
+    else if (!ta0 && tb0) gemm_ks4_pair_kernel<0, 1><<<n0 + n1, 256, 0, stream>>>(a0, a1, n0);
+    else gemm_ks4_pair_kernel<0, 0><<<n0 + n1, 256, 0, stream>>>(a0, a1, n0);
+    SPOT_CHECK_LAUNCH("gemm_pair");
     return SPOT_OK;
 }

@@ -162,21 +162,31 @@ __device__ __forceinline__ void softmax_block(bool check, f32x16& s, f32x16& o, 
     }
 }
 
+// One call of the forward kernels' arguments (a launch may carry two, see mha_fwd_pair_kernel)
+struct MhaFwdArgs {
+    const float* Q; long ldq; const float* K; long ldk; const float* V; long ldv;
+    float* O; long ldo; float* LSE; const unsigned char* kpm;
+    int Lq, Lk, H; float scale; unsigned drop_thr, drop_seed; float drop_scale;
+    int nsplit; float* part_o; float* part_ml;
+};
+
+// (bx, head, b, nb): the workgroup's index along the (query tile, key range) axis, its head, clip and the clip count
 template <bool BF16>
-__global__ __launch_bounds__(256, 3) void mha_fwd_kernel(
-    const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
-    float* __restrict__ O, long ldo, float* __restrict__ LSE, const unsigned char* __restrict__ kpm,
-    int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed, float drop_scale,
-    int nsplit = 1, float* __restrict__ part_o = nullptr, float* __restrict__ part_ml = nullptr) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * KP];
+__device__ __forceinline__ void mha_fwd_body(const MhaFwdArgs& A, int bx, int head, int b, int nb, float* lds) {
+    const float* __restrict__ Q = A.Q; const float* __restrict__ K = A.K; const float* __restrict__ V = A.V;
+    float* __restrict__ O = A.O; float* __restrict__ LSE = A.LSE; const unsigned char* __restrict__ kpm = A.kpm;
+    const long ldq = A.ldq, ldk = A.ldk, ldv = A.ldv, ldo = A.ldo;
+    const int Lq = A.Lq, Lk = A.Lk, H = A.H, nsplit = A.nsplit;
+    const float scale = A.scale, drop_scale = A.drop_scale;
+    const unsigned drop_thr = A.drop_thr, drop_seed = A.drop_seed;
+    float* __restrict__ part_o = A.part_o; float* __restrict__ part_ml = A.part_ml;
     auto Ks = [&](int buf) { return lds + buf * 2 * KT * KP; };
     auto Vs = [&](int buf) { return lds + buf * 2 * KT * KP + KT * KP; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
-    const int head = blockIdx.y, b = blockIdx.z;
-    // with nsplit > 1 the keys are cut in nsplit ranges of whole tiles, one workgroup each: blockIdx.x = tile * nsplit + s
-    const int split = (int)blockIdx.x % nsplit;
-    const int q = ((int)blockIdx.x / nsplit) * 128 + wave * 32 + l31;
+    // with nsplit > 1 the keys are cut in nsplit ranges of whole tiles, one workgroup each: bx = tile * nsplit + s
+    const int split = bx % nsplit;
+    const int q = (bx / nsplit) * 128 + wave * 32 + l31;
     const bool qok = q < Lq;
     const float c = scale * 1.4426950408889634f;   // Q is pre-multiplied by c: scores live in the log2 domain
     const unsigned qs = ((unsigned)q << 16) ^ attn_stream_key(drop_seed, (unsigned)(b * H + head));
@@ -260,12 +270,12 @@ __global__ __launch_bounds__(256, 3) void mha_fwd_kernel(
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     if (part_o) {                // this key range's unnormalised sums, its running maximum (log2 domain) and row sum
         if (qok) {
-            float* op = part_o + (((long)split * gridDim.z + b) * Lq + q) * ((long)H * DH) + head * DH;
+            float* op = part_o + (((long)split * nb + b) * Lq + q) * ((long)H * DH) + head * DH;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
                 *reinterpret_cast<float4*>(op + 8 * gq + 4 * h) = make_float4(o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]);
             if (h == 0) {
-                float* mp = part_ml + ((((long)split * gridDim.z + b) * H + head) * Lq + q) * 2;
+                float* mp = part_ml + ((((long)split * nb + b) * H + head) * Lq + q) * 2;
                 mp[0] = m_run;
                 mp[1] = l_tot;
             }
@@ -281,6 +291,20 @@ __global__ __launch_bounds__(256, 3) void mha_fwd_kernel(
                 make_float4(o[4 * gq] * inv, o[4 * gq + 1] * inv, o[4 * gq + 2] * inv, o[4 * gq + 3] * inv);
         if (LSE && h == 0) LSE[((long)b * H + head) * Lq + q] = m_run * 0.6931471805599453f + logf(l_tot);
     }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 3) void mha_fwd_kernel(MhaFwdArgs A) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * KP];
+    mha_fwd_body<BF16>(A, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, lds);
+}
+
+// Two independent calls of the same head count in one launch (one clip each: the template and the search stream of a
+// fusion layer); workgroups 0 .. n0-1 along x belong to the first.
+__global__ __launch_bounds__(256, 3) void mha_fwd_pair_kernel(MhaFwdArgs A0, MhaFwdArgs A1, int n0) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * KP];
+    if ((int)blockIdx.x < n0) mha_fwd_body<false>(A0, blockIdx.x, blockIdx.y, 0, 1, lds);
+    else mha_fwd_body<false>(A1, (int)blockIdx.x - n0, blockIdx.y, 0, 1, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -423,8 +447,8 @@ static int mha_fwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
     if (bf16) {
         // the matrix work shrinks 16-fold: the loop is vector-bound and gains nothing from pairing matrix with vector phases
         dim3 grid((Lq + 127) / 128, nhead, B);
-        mha_fwd_kernel<true><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk,
-                                                       nhead, scale, thr, drop_seed, dscale);
+        mha_fwd_kernel<true><<<grid, 256, 0, stream>>>(MhaFwdArgs{q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk,
+                                                       nhead, scale, thr, drop_seed, dscale, 1, nullptr, nullptr});
     } else if (Lq >= 512 && (long)((Lq + 255) / 256) * nhead * B >= 512) {
         // 256-query workgroups need enough of them to fill the chip; short query streams keep the 128-query kernel
         dim3 grid((Lq + 255) / 256, nhead, B);
@@ -432,8 +456,8 @@ static int mha_fwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
                                                     scale, thr, drop_seed, dscale);
     } else {
         dim3 grid((Lq + 127) / 128, nhead, B);
-        mha_fwd_kernel<false><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk,
-                                                        nhead, scale, thr, drop_seed, dscale);
+        mha_fwd_kernel<false><<<grid, 256, 0, stream>>>(MhaFwdArgs{q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk,
+                                                        nhead, scale, thr, drop_seed, dscale, 1, nullptr, nullptr});
     }
     SPOT_CHECK_LAUNCH("mha_fwd");
     return SPOT_OK;
@@ -786,9 +810,9 @@ extern "C" int spot_mha_dropout_mask(unsigned char* mask, int B, int nhead, int 
 // Inference only: no dropout, no log-sum-exp output.
 // ---------------------------------------------------------------------------
 namespace {
-__global__ __launch_bounds__(256) void mha_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                        float* __restrict__ O, long ldo, int B, int Lq, int H, int nsplit) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // (b, q, head, group of 4 features)
+__device__ __forceinline__ void mha_merge_body(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                               float* __restrict__ O, long ldo, int B, int Lq, int H, int nsplit, int bid) {
+    const long idx = (long)bid * 256 + threadIdx.x;                 // (b, q, head, group of 4 features)
     const long total = (long)B * Lq * H * (DH / 4);
     if (idx >= total) return;
     const int g4 = (int)(idx % (DH / 4)), head = (int)(idx / (DH / 4) % H);
@@ -807,6 +831,17 @@ __global__ __launch_bounds__(256) void mha_merge_kernel(const float* __restrict_
     }
     const float inv = 1.f / den;
     *reinterpret_cast<float4*>(O + row * ldo + head * DH + 4 * g4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+__global__ __launch_bounds__(256) void mha_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                        float* __restrict__ O, long ldo, int B, int Lq, int H, int nsplit) {
+    mha_merge_body(part_o, part_ml, O, ldo, B, Lq, H, nsplit, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void mha_merge_pair_kernel(const float* __restrict__ po0, const float* __restrict__ pm0,
+                                                             float* __restrict__ O0, long ldo0, int Lq0, int ns0,
+                                                             const float* __restrict__ po1, const float* __restrict__ pm1,
+                                                             float* __restrict__ O1, long ldo1, int Lq1, int ns1, int H, int n0) {
+    if ((int)blockIdx.x < n0) mha_merge_body(po0, pm0, O0, ldo0, 1, Lq0, H, ns0, blockIdx.x);
+    else mha_merge_body(po1, pm1, O1, ldo1, 1, Lq1, H, ns1, (int)blockIdx.x - n0);
 }
 }  // namespace
 
@@ -830,12 +865,41 @@ extern "C" int spot_mha_fwd_splitk_f32(const float* q, long ldq, const float* k,
     float* part_o = ws;
     float* part_ml = ws + (long)nsplit * B * Lq * nhead * DH;
     dim3 grid(((Lq + 127) / 128) * nsplit, nhead, B);
-    mha_fwd_kernel<false><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, nullptr, key_padding_mask, Lq, Lk,
-                                                    nhead, scale, 0u, 0u, 1.f, nsplit, part_o, part_ml);
+    mha_fwd_kernel<false><<<grid, 256, 0, stream>>>(MhaFwdArgs{q, ldq, k, ldk, v, ldv, out, ldo, nullptr, key_padding_mask, Lq, Lk,
+                                                    nhead, scale, 0u, 0u, 1.f, nsplit, part_o, part_ml});
     SPOT_CHECK_LAUNCH("mha_fwd_splitk");
     const long total = (long)B * Lq * nhead * (DH / 4);
     mha_merge_kernel<<<spot_ceil_div(total, 256), 256, 0, stream>>>(part_o, part_ml, out, ldo, B, Lq, nhead, nsplit);
     SPOT_CHECK_LAUNCH("mha_fwd_splitk(merge)");
+    return SPOT_OK;
+}
+
+// Two split-key forwards of one clip each in two launches instead of four (forward pair, merge pair): the template and
+// the search stream of a fusion layer.  Same arithmetic as two spot_mha_fwd_splitk_f32 calls.
+extern "C" int spot_mha_fwd_splitk_pair_f32(const float* q0, long ldq0, const float* k0, long ldk0, const float* v0, long ldv0,
+                                            float* out0, long ldo0, const unsigned char* kpm0, float* ws0, int nsplit0, int Lq0,
+                                            int Lk0, const float* q1, long ldq1, const float* k1, long ldk1, const float* v1,
+                                            long ldv1, float* out1, long ldo1, const unsigned char* kpm1, float* ws1, int nsplit1,
+                                            int Lq1, int Lk1, int nhead, int head_dim, float scale, hipStream_t stream) {
+    SPOT_CHECK_ARG(q0 && k0 && v0 && out0 && ws0 && q1 && k1 && v1 && out1 && ws1, "mha_fwd_splitk_pair: null pointer");
+    SPOT_CHECK_ARG(head_dim == DH, "mha_fwd_splitk_pair: head_dim=%d unsupported (this build handles 32)", head_dim);
+    SPOT_CHECK_ARG(Lq0 > 0 && Lk0 > 0 && Lq1 > 0 && Lk1 > 0 && nhead > 0 && nhead <= 65535 && nsplit0 >= 1 && nsplit0 <= 64 &&
+                       nsplit1 >= 1 && nsplit1 <= 64, "mha_fwd_splitk_pair: bad shape");
+    SPOT_CHECK_ARG(((ldq0 | ldk0 | ldv0 | ldo0 | ldq1 | ldk1 | ldv1 | ldo1) % 4) == 0 &&
+                       (((uintptr_t)q0 | (uintptr_t)k0 | (uintptr_t)v0 | (uintptr_t)out0 | (uintptr_t)ws0 | (uintptr_t)q1 |
+                         (uintptr_t)k1 | (uintptr_t)v1 | (uintptr_t)out1 | (uintptr_t)ws1) & 15) == 0,
+                   "mha_fwd_splitk_pair: operands must be 16-byte aligned with row strides that are multiples of 4");
+    float* po0 = ws0; float* pm0 = ws0 + (long)nsplit0 * Lq0 * nhead * DH;
+    float* po1 = ws1; float* pm1 = ws1 + (long)nsplit1 * Lq1 * nhead * DH;
+    const int n0 = ((Lq0 + 127) / 128) * nsplit0, n1 = ((Lq1 + 127) / 128) * nsplit1;
+    mha_fwd_pair_kernel<<<dim3(n0 + n1, nhead, 1), 256, 0, stream>>>(
+        MhaFwdArgs{q0, ldq0, k0, ldk0, v0, ldv0, out0, ldo0, nullptr, kpm0, Lq0, Lk0, nhead, scale, 0u, 0u, 1.f, nsplit0, po0, pm0},
+        MhaFwdArgs{q1, ldq1, k1, ldk1, v1, ldv1, out1, ldo1, nullptr, kpm1, Lq1, Lk1, nhead, scale, 0u, 0u, 1.f, nsplit1, po1, pm1}, n0);
+    SPOT_CHECK_LAUNCH("mha_fwd_splitk_pair");
+    const int m0 = (int)spot_ceil_div((long)Lq0 * nhead * (DH / 4), 256), m1 = (int)spot_ceil_div((long)Lq1 * nhead * (DH / 4), 256);
+    mha_merge_pair_kernel<<<m0 + m1, 256, 0, stream>>>(po0, pm0, out0, ldo0, Lq0, nsplit0, po1, pm1, out1, ldo1, Lq1, nsplit1,
+                                                      nhead, m0);
+    SPOT_CHECK_LAUNCH("mha_fwd_splitk_pair(merge)");
     return SPOT_OK;
 }
 

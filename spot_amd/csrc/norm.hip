@@ -13,13 +13,15 @@ namespace {
 
 constexpr int MAXV = 4;   // float4 per lane: C <= 1024
 
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ y,
-                                                     float* __restrict__ mean, float* __restrict__ rstd, long rows,
-                                                     int C, float eps) {
+// (bid, nblocks): this workgroup's index among the nblocks that walk the rows (a launch for two tensors hands each
+//  workgroup its tensor and its index there)
+__device__ __forceinline__ void ln_fwd_body(const float* __restrict__ x, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, float* __restrict__ y,
+                                            float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                            int C, float eps, int bid, int nblocks) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
-    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    for (long row = (long)bid * 4 + wave; row < rows; row += (long)nblocks * 4) {
         const float4* xp = reinterpret_cast<const float4*>(x + row * C);
         float4 v[MAXV];
         float s = 0.f;
@@ -55,6 +57,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             if (rstd) rstd[row] = rs;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                                     int C, float eps) {
+    ln_fwd_body(x, gamma, beta, y, mean, rstd, rows, C, eps, blockIdx.x, gridDim.x);
+}
+
+// two independent tensors in one launch (inference: no saved statistics); workgroups 0 .. n0-1 take the first
+__global__ __launch_bounds__(256) void ln_fwd_pair_kernel(const float* __restrict__ x0, const float* __restrict__ g0,
+                                                          const float* __restrict__ b0, float* __restrict__ y0, long rows0,
+                                                          const float* __restrict__ x1, const float* __restrict__ g1,
+                                                          const float* __restrict__ b1, float* __restrict__ y1, long rows1,
+                                                          int C, float eps0, float eps1, int n0) {
+    if ((int)blockIdx.x < n0) ln_fwd_body(x0, g0, b0, y0, nullptr, nullptr, rows0, C, eps0, blockIdx.x, n0);
+    else ln_fwd_body(x1, g1, b1, y1, nullptr, nullptr, rows1, C, eps1, (int)blockIdx.x - n0, (int)gridDim.x - n0);
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;  dgamma = sum dy * xhat;  dbeta = sum dy
@@ -243,6 +262,23 @@ extern "C" int spot_layernorm_fwd_f32(const float* x, const float* gamma, const 
     if (grid > 8192) grid = 8192;
     ln_fwd_kernel<<<(int)grid, 256, 0, stream>>>(x, gamma, beta, y, mean, rstd, rows, C, eps);
     SPOT_CHECK_LAUNCH("layernorm_fwd");
+    return SPOT_OK;
+}
+
+extern "C" int spot_layernorm_fwd_pair_f32(const float* x0, const float* gamma0, const float* beta0, float* y0, long rows0,
+                                           float eps0, const float* x1, const float* gamma1, const float* beta1, float* y1,
+                                           long rows1, float eps1, int C, hipStream_t stream) {
+    SPOT_CHECK_ARG(x0 && gamma0 && beta0 && y0 && x1 && gamma1 && beta1 && y1, "layernorm_fwd_pair: null pointer");
+    SPOT_CHECK_ARG(rows0 > 0 && rows1 > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXV,
+                   "layernorm_fwd_pair: rows must be positive and C=%d a multiple of 4, <= %d", C, 256 * MAXV);
+    SPOT_CHECK_ARG((((uintptr_t)x0 | (uintptr_t)y0 | (uintptr_t)gamma0 | (uintptr_t)beta0 | (uintptr_t)x1 | (uintptr_t)y1 |
+                     (uintptr_t)gamma1 | (uintptr_t)beta1) & 15) == 0, "layernorm_fwd_pair: buffers must be 16-byte aligned");
+    long n0 = (rows0 + 3) / 4, n1 = (rows1 + 3) / 4;
+    if (n0 > 4096) n0 = 4096;
+    if (n1 > 4096) n1 = 4096;
+    ln_fwd_pair_kernel<<<(int)(n0 + n1), 256, 0, stream>>>(x0, gamma0, beta0, y0, rows0, x1, gamma1, beta1, y1, rows1, C, eps0,
+                                                          eps1, (int)n0);
+    SPOT_CHECK_LAUNCH("layernorm_fwd_pair");
     return SPOT_OK;
 }
 

@@ -65,6 +65,9 @@ class _AttentionParams(nn.Module):
                              p_attn, p_out, self.attn_bf16)
 
 
+# One-clip inference under ops.frozen_weights (the online tracker): issue the two streams' launches in pairs
+# (see FeatureFusionLayer._forward_paired).
+PAIRED_LAUNCHES = True
 # Run the template stream of every fusion layer on a second HIP stream (see _forward_two_streams).
 TWO_STREAMS = True
 _SIDE_STREAMS = {}
@@ -108,6 +111,8 @@ class FeatureFusionLayer(nn.Module):
 
     def forward(self, src1, src2, kpm1=None, kpm2=None, pos_src1=None, pos_src2=None):
         p = self.dropout if self.training else 0.0      # dropout11..23, dropout1/2 of the reference
+        if PAIRED_LAUNCHES and src1.is_cuda and src1.shape[0] == 1 and ops.frozen_weights._active and not torch.is_grad_enabled():
+            return self._forward_paired(src1, src2, kpm1, kpm2, pos_src1, pos_src2)
         if TWO_STREAMS and src1.is_cuda:
             return self._forward_two_streams(src1, src2, kpm1, kpm2, pos_src1, pos_src2, p)
         src1 = self.norm11(self.self_attn1(src1, src1, pos_src1, pos_src1, kpm1, True, True, p))
@@ -120,6 +125,26 @@ class FeatureFusionLayer(nn.Module):
         src2 = self.norm22(z2)
         src2 = self.norm23(_ffn(src2, self.linear21, self.linear22, p))
         return src1, src2
+
+    def _forward_paired(self, src1, src2, kpm1, kpm2, pos_src1, pos_src2):
+        """One clip, inference (the online tracker): the launches of such a pass last as long as their latencies, so
+        the two streams' kernels go out in pairs - the library calls of either stream are collected, then issued side
+        by side through the two-problem entry points (one launch for both projections, both attention cores, both
+        LayerNorms ...).  The arithmetic of each call is unchanged."""
+        from . import lib
+        with lib.record() as ra:
+            a1 = self.norm11(self.self_attn1(src1, src1, pos_src1, pos_src1, kpm1, True, True, 0.0))
+        with lib.record() as rb:
+            a2 = self.norm21(self.self_attn2(src2, src2, pos_src2, pos_src2, kpm2, True, True, 0.0))
+        lib.run_paired(ra.calls, rb.calls)
+        with lib.record() as ra:
+            z1 = self.multihead_attn1(a1, a2, pos_src1, pos_src2, kpm2, True, False, 0.0)
+            out1 = self.norm13(_ffn(self.norm12(z1), self.linear11, self.linear12, 0.0))
+        with lib.record() as rb:
+            z2 = self.multihead_attn2(a2, a1, pos_src2, pos_src1, kpm1, True, False, 0.0)
+            out2 = self.norm23(_ffn(self.norm22(z2), self.linear21, self.linear22, 0.0))
+        lib.run_paired(ra.calls, rb.calls)
+        return out1, out2
 
     def _forward_two_streams(self, src1, src2, kpm1, kpm2, pos_src1, pos_src2, p):
         """Same computation with the template stream (256 tokens per clip) on a second HIP stream: its kernels

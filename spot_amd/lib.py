@@ -101,6 +101,9 @@ SIGNATURES = {
     "spot_conv3x3_winograd_wgrad_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
     "spot_mha_fwd_splitk_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp] + [i32] * 6 + [f32, vp],
+    "spot_mha_fwd_splitk_pair_f32": ([vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32] * 2) + [i32, i32, f32, vp],
+    "spot_layernorm_fwd_pair_f32": [vp, vp, vp, vp, i64, f32, vp, vp, vp, vp, i64, f32, i32, vp],
+    "spot_gemm_pair_f32": [vp, vp, vp],
     "spot_mha_fwd_splitk_noalloc_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp] + [i32] * 6 + [f32, vp],
     "spot_mha_bwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64,
                          i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
@@ -164,8 +167,76 @@ def check(rc, what=""):
         raise RuntimeError("spot_hip %s failed (%d): %s" % (what, rc, msg))
 
 
+_recording = None     # a list while launches are being collected instead of issued (see record / run_paired)
+_keeping = None       # the tensors whose addresses the collected launches carry (kept alive until they are issued)
+
+
+def keep(*tensors):
+    """While launches are being collected, hold on to the tensors they address: a buffer released before its launch
+    goes out could be handed to another collected launch, and the two would then run on the same memory."""
+    if _keeping is not None:
+        _keeping.extend(t for t in tensors if t is not None)
+
+
 def call(name, *args):
     """Call a C-ABI entry point and raise on a non-zero status."""
+    if _recording is not None:
+        _recording.append((name, args))
+        return
     rc = getattr(_lib or load(), name)(*args)
     if rc != 0:
         check(rc, name)
+
+
+class record:
+    """Collects the library calls made inside the block instead of issuing them; `.calls` holds (name, args) in order.
+    The block must consist of library launches and allocations only: anything else the framework runs on the device
+    inside it would execute before the collected launches.  The object keeps the buffers of its calls alive: hold it
+    until the calls have been issued."""
+
+    def __enter__(self):
+        global _recording, _keeping
+        self._prev, self.calls, self.tensors = (_recording, _keeping), [], []
+        _recording, _keeping = self.calls, self.tensors
+        return self
+
+    def __exit__(self, *exc):
+        global _recording, _keeping
+        _recording, _keeping = self._prev
+        return False
+
+
+def _pair_gemm(a, b):
+    return "spot_gemm_pair_f32", (a[0], b[0], a[1])
+
+
+def _pair_layernorm(a, b):
+    # (x, gamma, beta, y, mean, rstd, rows, C, eps, stream): inference calls keep no statistics
+    if a[4] is not None or a[5] is not None or b[4] is not None or b[5] is not None or a[7] != b[7]:
+        return None
+    return "spot_layernorm_fwd_pair_f32", (a[0], a[1], a[2], a[3], a[6], a[8], b[0], b[1], b[2], b[3], b[6], b[8], a[7], a[9])
+
+
+def _pair_mha_splitk(a, b):
+    # (q, ldq, k, ldk, v, ldv, out, ldo, kpm, ws, nsplit, B, Lq, Lk, nhead, head_dim, scale, stream)
+    if a[11] != 1 or b[11] != 1 or a[14:17] != b[14:17]:
+        return None
+    return "spot_mha_fwd_splitk_pair_f32", (a[:11] + (a[12], a[13]) + b[:11] + (b[12], b[13]) + (a[14], a[15], a[16], a[17]))
+
+
+_PAIRS = {"spot_gemm_f32": _pair_gemm, "spot_layernorm_fwd_f32": _pair_layernorm, "spot_mha_fwd_splitk_f32": _pair_mha_splitk}
+
+
+def run_paired(calls_a, calls_b):
+    """Issue two recorded call sequences side by side: calls at the same position that name the same entry point go
+    out through its two-problem variant (one launch where the library can), everything else one after the other."""
+    n = min(len(calls_a), len(calls_b))
+    for (na, aa), (nb, ab) in zip(calls_a[:n], calls_b[:n]):
+        merged = _PAIRS[na](aa, ab) if na == nb and na in _PAIRS else None
+        if merged is not None:
+            call(*((merged[0],) + tuple(merged[1])))
+        else:
+            call(na, *aa)
+            call(nb, *ab)
+    for name, args in calls_a[n:] + calls_b[n:]:
+        call(name, *args)

@@ -76,7 +76,11 @@ def next_seed():
 
 
 def _p(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    if t is None:
+        return None
+    if lib._keeping is not None:
+        lib._keeping.append(t)
+    return C.c_void_p(t.data_ptr())
 
 
 def _chk(t, dtype=torch.float32, name="tensor"):
@@ -530,6 +534,8 @@ def gemm(A, B, Cout, M, N, K, *, transA=False, transB=False, lda=None, ldb=None,
          ldres=0, strideRes=0, drop_p=0.0, drop_seed=0, tile=0, rowsum=None, rb_cols=0, bn=None, precision=None):
     """Raw access to spot_gemm_f32; tensors are only used for their base pointers."""
     d = GemmDesc()
+    if lib._keeping is not None:
+        lib.keep(A, B, Cout, bias, rowbias, mask, residual, rowsum)
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
     d.M, d.N, d.K, d.batch = M, N, K, batch
     d.transA, d.transB = int(transA), int(transB)
@@ -819,14 +825,16 @@ class LayerNormFn(_Fn):
         x2 = _view2d(x.contiguous())
         rows, Cn = x2.shape
         y = torch.empty_like(x2)
-        mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
-        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        need = _wants(ctx)              # the row statistics are kept for backward only
+        mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if need else None
+        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device) if need else None
         lib.call("spot_layernorm_fwd_f32", _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, Cn,
                  float(eps), _st())
-        ctx.save_for_backward(x2, mean, rstd, gamma)
-        ctx.params = (gamma, beta)
-        if _sink(gamma) is not None and _sink(beta) is not None:
-            _sink_expect(gamma, beta)
+        if need:
+            ctx.save_for_backward(x2, mean, rstd, gamma)
+            ctx.params = (gamma, beta)
+            if _sink(gamma) is not None and _sink(beta) is not None:
+                _sink_expect(gamma, beta)
         return y.view_as(x)
 
     @staticmethod

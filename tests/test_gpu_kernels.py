@@ -963,6 +963,99 @@ def test_mha_forward_with_split_keys(ops, Lq, Lk, nsplit):
     np.testing.assert_allclose(auto.cpu().numpy(), one.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_two_problem_entry_points_equal_separate_calls(ops):
+    """The two-problem launches of one-clip inference (GEMM with 32x32 k-split tiles, LayerNorm, split-key attention +
+    merge) give, bit for bit, what the single-problem entry points give for either problem; a pair the library cannot
+    put in one launch (different tiles) still runs both."""
+    from spot_amd import lib as L
+    P = ops._p
+    # --- GEMM pair: x W^T + bias + residual, template rows (256) beside search rows (1024)
+    outs = {}
+    for tag, paired in (("single", False), ("pair", True)):
+        xa, wa, ba, ra = (G(det_input(n, sh, 5, -1, 1)) for n, sh in (("xa", (256, 256)), ("wa", (256, 256)), ("ba", (256,)), ("ra", (256, 256))))
+        xb, wb, bb, rb = (G(det_input(n, sh, 6, -1, 1)) for n, sh in (("xb", (1024, 256)), ("wb", (512, 256)), ("bb", (512,)), ("rb", (1024, 512))))
+        ya, yb = torch.empty(256, 256, device=DEV), torch.empty(1024, 512, device=DEV)
+        if paired:
+            with L.record() as r0:
+                ops.gemm(xa, wa, ya, 256, 256, 256, bias=ba, residual=ra, ldres=256, tile=32)
+            with L.record() as r1:
+                ops.gemm(xb, wb, yb, 1024, 512, 256, bias=bb, residual=rb, ldres=512, relu=True, tile=32)
+            assert len(r0.calls) == len(r1.calls) == 1
+            L.run_paired(r0.calls, r1.calls)
+        else:
+            ops.gemm(xa, wa, ya, 256, 256, 256, bias=ba, residual=ra, ldres=256, tile=32)
+            ops.gemm(xb, wb, yb, 1024, 512, 256, bias=bb, residual=rb, ldres=512, relu=True, tile=32)
+        outs[tag] = (ya.clone(), yb.clone())
+    assert torch.equal(outs["single"][0], outs["pair"][0]) and torch.equal(outs["single"][1], outs["pair"][1])
+    ref = T(det_input("xa", (256, 256), 5, -1, 1)).double() @ T(det_input("wa", (256, 256), 5, -1, 1)).double().T
+    ref = ref + T(det_input("ba", (256,), 5, -1, 1)).double() + T(det_input("ra", (256, 256), 5, -1, 1)).double()
+    np.testing.assert_allclose(outs["pair"][0].cpu().double().numpy(), ref.numpy(), rtol=0, atol=2e-4)
+    # a pair of different tiles falls back to two launches
+    xa, wa = G(det_input("xa", (256, 256), 5, -1, 1)), G(det_input("wa", (256, 256), 5, -1, 1))
+    y32, y64, y1, y2 = (torch.empty(256, 256, device=DEV) for _ in range(4))
+    with L.record() as r0:
+        ops.gemm(xa, wa, y32, 256, 256, 256, tile=32)
+    with L.record() as r1:
+        ops.gemm(xa, wa, y64, 256, 256, 256, tile=64)
+    L.run_paired(r0.calls, r1.calls)
+    ops.gemm(xa, wa, y1, 256, 256, 256, tile=32)
+    ops.gemm(xa, wa, y2, 256, 256, 256, tile=64)
+    assert torch.equal(y32, y1) and torch.equal(y64, y2)
+    # --- LayerNorm pair
+    xa, xb = G(det_input("lna", (256, 256), 7, -3, 3)), G(det_input("lnb", (1021, 256), 8, -3, 3))
+    ga, gb, ba, bb = (G(det_input(n, (256,), 9, 0.5, 1.5)) for n in ("ga", "gb", "ba", "bb"))
+    with torch.no_grad():
+        sa, sb = ops.layer_norm(xa, ga, ba, 1e-5), ops.layer_norm(xb, gb, bb, 1e-5)
+        with L.record() as r0:
+            pa = ops.layer_norm(xa, ga, ba, 1e-5)
+        with L.record() as r1:
+            pb = ops.layer_norm(xb, gb, bb, 1e-5)
+        L.run_paired(r0.calls, r1.calls)
+    assert torch.equal(sa, pa) and torch.equal(sb, pb)
+    # --- split-key attention pair (one clip each)
+    nh, dh = 8, 32
+    C = nh * dh
+    res = {}
+    for tag in ("single", "pair"):
+        got = []
+        recs = []
+        for (Lq, Lk, ns, seed) in ((256, 1024, 4, 11), (1024, 256, 3, 12)):
+            q, k, v = (G(det_input(n, (L_, C), seed, -2, 2)) for n, L_ in (("q", Lq), ("k", Lk), ("v", Lk)))
+            out = torch.empty((Lq, C), device=DEV)
+            ws = torch.empty((L.load().spot_mha_fwd_splitk_ws_floats(1, Lq, nh, ns),), device=DEV)
+            args = (P(q), C, P(k), C, P(v), C, P(out), C, None, P(ws), ns, 1, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), ops._st())
+            if tag == "single":
+                L.call("spot_mha_fwd_splitk_f32", *args)
+            else:
+                recs.append([("spot_mha_fwd_splitk_f32", args)])
+            got.append((out, q, k, v, ws))
+        if tag == "pair":
+            L.run_paired(recs[0], recs[1])
+        res[tag] = [g[0].clone() for g in got]
+    assert torch.equal(res["single"][0], res["pair"][0]) and torch.equal(res["single"][1], res["pair"][1])
+
+
+def test_collected_launches_keep_their_buffers(ops):
+    """Launches collected for pairing address buffers that the collecting code has already let go of: the collection
+    must keep them, or two collected launches end up on the same memory."""
+    from spot_amd import lib as L
+    x = G(det_input("x", (512, 256), 3, -1, 1))
+    w1, w2 = G(det_input("w1", (256, 256), 4, -0.2, 0.2)), G(det_input("w2", (256, 256), 5, -0.2, 0.2))
+
+    def chain(w):                               # two dependent products; the intermediate is released on return
+        h = ops.linear_fwd(x, w)
+        return ops.linear_fwd(h, w)
+    with torch.no_grad():
+        ref1, ref2 = chain(w1), chain(w2)
+        with L.record() as r0:
+            o1 = chain(w1)
+        with L.record() as r1:
+            o2 = chain(w2)
+        assert len(r0.tensors) > 0
+        L.run_paired(r0.calls, r1.calls)
+    assert torch.equal(o1, ref1) and torch.equal(o2, ref2)
+
+
 # --------------------------------------------------------------------------- position encoding, matcher, criterion
 def test_position_encoding_golden(golden):
     """The sine position encoding kernel against the reference's PositionEmbeddingSine: the unmasked 16x16 and 32x32
