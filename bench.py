@@ -175,27 +175,31 @@ class Cfg3Job:
 
 # timer key -> kernel symbol prefix in the profiles (template arguments: A layout, B layout, aligned operands, then
 # the workgroup tile and the row-sum flag, which the prefix leaves open)
-KERNEL_SYMBOLS = {"gemm_nt": "gemm_kernel<1, 1, true", "gemm_nn": "gemm_kernel<1, 0, true",
-                  "gemm_tn": "gemm_kernel<0, 0, true", "gemm_tt": "gemm_kernel<0, 1, true",
-                  "mha_fwd": "mha_fwd_pp_kernel", "mha_bwd": "mha_bwd_kernel<false>"}
+# (whole tiles of aligned operands run on gemm_ring_kernel<A layout, B layout, tile, row sums>, the rest on gemm_kernel)
+KERNEL_SYMBOLS = {"gemm_nt": ("gemm_ring_kernel<1, 1", "gemm_kernel<1, 1, true"),
+                  "gemm_nn": ("gemm_ring_kernel<1, 0", "gemm_kernel<1, 0, true"),
+                  "gemm_tn": ("gemm_ring_kernel<0, 0", "gemm_kernel<0, 0, true"),
+                  "gemm_tt": ("gemm_ring_kernel<0, 1", "gemm_kernel<0, 1, true"),
+                  "mha_fwd": ("mha_fwd_pp_kernel", "mha_fwd_kernel<false>"), "mha_bwd": ("mha_bwd_kernel<false",)}
 
 
-TRAFFIC_FILE = "r2_traffic.json"
+TRAFFIC_FILE = "r3_traffic.json"
 
 
 def measured_traffic(key):
     """HBM bytes per launch of the kernel class (launch-weighted over its instantiations), from the committed
     counter passes over this same command (profiles/<TRAFFIC_FILE>, written by tools/collect_traffic.sh); None if
     no such measurement exists."""
-    symbol = KERNEL_SYMBOLS.get(key.split(" ")[0])
+    symbols = KERNEL_SYMBOLS.get(key.split(" ")[0])
+    label = None if symbols is None else " | ".join(x + ", ...>" for x in symbols)
     path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-    if symbol is None or not os.path.exists(path):
-        return None, symbol
-    rows = [v for k, v in json.load(open(path))["kernels"].items() if k.startswith(symbol)]
+    if symbols is None or not os.path.exists(path):
+        return None, label
+    rows = [v for k, v in json.load(open(path))["kernels"].items() if k.startswith(symbols)]
     n = sum(r["launches"] for r in rows)
     if n == 0:
-        return None, symbol
-    return round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n), symbol + ", ...>"
+        return None, label
+    return round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n), label
 
 
 def cpu_baseline(args):
@@ -284,7 +288,7 @@ def main_cfg3(args, rank, world, collective):
             dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
             a = dom[1]
             ach = a["work"] / (a["ms"] * 1e-3) / 1e12
-            roofline = {"kernel": dom[0], "symbol": KERNEL_SYMBOLS.get(dom[0], dom[0]) + ", ...>", "bound": "mfma",
+            roofline = {"kernel": dom[0], "symbol": measured_traffic(dom[0])[1] or dom[0], "bound": "mfma",
                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "launches": a["launches"],
                         "avg_us": round(a["ms"] * 1e3 / a["launches"], 2), "flops_per_launch": a["work"] / a["launches"]}

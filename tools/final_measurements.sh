@@ -27,6 +27,7 @@ if [ "$1" = "stage2" ]; then
 rm -f $O/microbench.txt
 for mode in "0 0" "0 0.1" "1 0.1"; do set -- $mode; SPOT_MB_BF16=$1 SPOT_MB_DROP=$2 timeout -k 10 100 python3 tools/microbench.py mha >> $O/microbench.txt 2>&1 || exit 1; done
 timeout -k 10 200 python3 tools/microbench.py gemm >> $O/microbench.txt 2>&1 || exit 1
+timeout -k 10 200 python3 tools/microbench.py gemm_tiles >> $O/microbench.txt 2>&1 || exit 1
 timeout -k 10 200 python3 tools/microbench.py gemm_bf16x3 >> $O/microbench.txt 2>&1 || exit 1
 timeout -k 10 100 python3 tools/microbench.py xcorr >> $O/microbench.txt 2>&1 || exit 1
 timeout -k 10 100 python3 tools/microbench.py norm >> $O/microbench.txt 2>&1 || exit 1

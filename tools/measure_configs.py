@@ -94,17 +94,7 @@ def cfg5():
     ho = hx - hz + 1
     fwd_bytes = 4.0 * (sum(x.numel() for x in xs) + sum(z.numel() for z in zs) + B * Cn * ho * ho)
 
-    def timeit(fn, iters=20):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(iters):
-            fn()
-        e.record()
-        torch.cuda.synchronize()
-        return s.elapsed_time(e) / iters * 1e-3
+    from tools.microbench import timeit          # clocks brought up first, median of five timed runs
 
     tf = timeit(lambda: ops.groupdw(zs, xs, w))
     for t in xs + zs + [w]:

@@ -261,6 +261,24 @@ def main():
     out.append("# per class over the window (per step): launches, kernel ms, launches with < %d workgroups" % CUS)
     for k, a in sorted(by.items(), key=lambda kv: -kv[1][1])[:24]:
         out.append("  %-24s %6.1f %8.3f %6.1f" % (k, a[0] / n, a[1] / n / 1e6, a[2] / n))
+    # how much of each class's kernel time passes with no other kernel in flight (the matrix pipes idle under a
+    # memory-bound kernel that runs alone, the memory system under a matrix-bound one)
+    ev = []
+    for r in rows:
+        ev.append((r["s"], 1, klass(r["name"])))
+        ev.append((r["e"], -1, klass(r["name"])))
+    ev.sort()
+    active, alone, beside, last = defaultdict(int), defaultdict(float), defaultdict(float), ev[0][0]
+    for t, d, c in ev:
+        live = [(k, v) for k, v in active.items() if v]
+        tot = sum(v for _, v in live)
+        for k, v in live:
+            (alone if tot == 1 else beside)[k] += (t - last) * v
+        active[c] += d
+        last = t
+    out.append("# per class (per step): kernel ms with no other kernel in flight / beside at least one other kernel")
+    for k in sorted(set(alone) | set(beside), key=lambda k: -(alone[k] + beside[k]))[:16]:
+        out.append("  %-24s %8.3f %8.3f" % (k, alone[k] / n / 1e6, beside[k] / n / 1e6))
     print("\n".join(out))
 
 

@@ -38,7 +38,7 @@ def main():
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {}
     for k in sorted(set(fetch) | set(write)):
-        if not any(t in k for t in ("gemm_kernel", "mha_", "ema_kernel", "ln_", "bn_", "groupdw", "colsum")):
+        if not any(t in k for t in ("gemm_kernel", "gemm_ring_kernel", "gemm_ks4", "mha_", "ema_kernel", "ln_", "bn_", "groupdw", "colsum", "wino_")):
             continue
         nf, f = fetch.get(k, (0, 0.0))
         nw, w = write.get(k, (0, 0.0))
