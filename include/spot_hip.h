@@ -348,11 +348,17 @@ int spot_channel_sum_f32(const float* x, int B, int C, long HW, float* out, hipS
  * lse [B,nhead,Lq] (log-sum-exp of the scaled scores, NULL to skip; needed by the backward);
  * key_padding_mask [B,Lk] bytes, non-zero = ignore key, or NULL.  head_dim must be 32.
  * drop_p > 0: dropout on the attention probabilities (nn.MultiheadAttention(dropout=...), :121,172-175) with a
- * counter-based mask of (drop_seed, clip, head, query, key); the backward regenerates it from the same seed. */
+ * counter-based mask of (drop_seed, clip, head, query, key).
+ * drop_bits (NULL, or spot_mha_drop_bits_words(B, nhead, Lq, Lk) 32-bit words): with drop_p > 0 the forward also
+ * writes the mask it drew, one bit per (query, key), for the backward call, which then spends two instructions per
+ * element on the mask instead of recomputing the hash (1024 x 1024, 40 clips: backward 1137 -> 1078 us, forward
+ * 434 -> 445 us).  A backward
+ * call given NULL regenerates the mask from the seed; both give the same gradients. */
+long spot_mha_drop_bits_words(int B, int nhead, int Lq, int Lk);
 int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                      float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B,
                      int Lq, int Lk, int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed,
-                     hipStream_t stream);
+                     unsigned* drop_bits, hipStream_t stream);
 
 /* The same forward for grids too small to fill the chip (the online tracker: one clip): the keys are cut in nsplit
  * ranges, one workgroup each, and merged by a second kernel.  Inference only (no dropout, no lse).  ws:
@@ -389,19 +395,20 @@ int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long ldk, const f
                      const float* out, long ldo, const float* d_out, long lddo, const float* lse,
                      const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq,
                      float* dk, long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead,
-                     int head_dim, float scale, float drop_p, unsigned drop_seed, hipStream_t stream);
+                     int head_dim, float scale, float drop_p, unsigned drop_seed, const unsigned* drop_bits,
+                     hipStream_t stream);
 /* Same contracts as spot_mha_fwd_f32 / spot_mha_bwd_f32, with the five matrix products taken in bf16
  * (operands rounded to bf16 in registers, fp32 accumulation, fp32 softmax): the "bf16 MFMA attention" training
  * configuration.  Inputs, outputs and saved statistics stay fp32. */
 int spot_mha_fwd_bf16(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                       float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B, int Lq,
                       int Lk, int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed,
-                      hipStream_t stream);
+                      unsigned* drop_bits, hipStream_t stream);
 int spot_mha_bwd_bf16(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                       const float* out, long ldo, const float* d_out, long lddo, const float* lse,
                       const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq, float* dk,
                       long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead, int head_dim,
-                      float scale, float drop_p, unsigned drop_seed, hipStream_t stream);
+                      float scale, float drop_p, unsigned drop_seed, const unsigned* drop_bits, hipStream_t stream);
 /* The mask the two calls above use, as bytes [B,nhead,Lq,Lk] (1 = kept); for host-side verification. */
 int spot_mha_dropout_mask(unsigned char* mask, int B, int nhead, int Lq, int Lk, float drop_p,
                           unsigned drop_seed, hipStream_t stream);

@@ -98,6 +98,12 @@ __device__ __forceinline__ bool attn_keep(unsigned sbh, unsigned q, unsigned key
     const unsigned bits = attn_mix(((q << 16) | (key & ~1u)) ^ sbh);
     return ((key & 1u) ? bits >> 16 : bits & 0xffffu) >= thr16;
 }
+// Keep bits for the backward pass.  A forward pass that is followed by a backward writes the mask it drew as one bit
+// per (query, key): 32-bit word [clip*head][query tile of 32][key tile of 32][query in tile] holds the 32 keys of the
+// tile for one query, in the order the forward's lanes own them: the low half belongs to the lane half h = 0, the
+// high half to h = 1, and inside a half accumulator element e (key acc_row(e, h) of the tile) sits at bit 15 - e.
+// The backward then spends two instructions per element (bit-field extract, and) instead of the hash.
+__device__ __forceinline__ long attn_bits_words(int Lq, int Lk) { return (long)((Lq + 31) / 32) * ((Lk + 31) / 32) * 32; }
 // 16-bit threshold of the pair hash from the library-wide 32-bit one (0 = dropout off; a rate below 2^-16 rounds up)
 static inline unsigned attn_threshold(float p) {
     const unsigned t = spot_drop_threshold(p);
@@ -117,8 +123,15 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 // below 2^(LAZY_TAU + 16): the normalised output and the log-sum-exp do not depend on the reference.
 // check = true (workgroup-uniform) applies the bounds / key-padding tests first.
 constexpr float LAZY_TAU = 8.f;
+// packed = 2 * packed + (this lane's bit of mask): one add with a comparison's lane mask as carry-in (the compiler's
+// own sequence for packing comparison results is a select, a shift and an or per bit)
+__device__ __forceinline__ void push_bit(unsigned& packed, unsigned long long mask) {
+    unsigned long long carry_out;
+    asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(packed), "=s"(carry_out) : "s"(mask));
+}
 __device__ __forceinline__ void softmax_block(bool check, f32x16& s, f32x16& o, float& m_ref, float& l_run, int key0, int h, int Lk,
-                                              const unsigned char* mb, unsigned qs, unsigned drop_thr, float drop_scale) {
+                                              const unsigned char* mb, unsigned qs, unsigned drop_thr, float drop_scale,
+                                              unsigned short* keep_out = nullptr) {
     if (check) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -153,11 +166,21 @@ __device__ __forceinline__ void softmax_block(bool check, f32x16& s, f32x16& o, 
         // keys of accumulator elements (e, e + 1), e even: key0 + 4h + r, r = acc_row(e, 0) even, and r + 1
         const unsigned x0 = qs ^ (unsigned)(key0 + 4 * h);   // low 16 bits: key
         s = s * drop_scale;
+        unsigned long long keep[16];               // lane masks of the comparisons
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
             const unsigned bits = attn_mix(x0 ^ (unsigned)acc_row(e, 0));
-            s[e] = (bits & 0xffffu) >= drop_thr ? s[e] : 0.f;
-            s[e + 1] = (bits >> 16) >= drop_thr ? s[e + 1] : 0.f;
+            const bool k0 = (bits & 0xffffu) >= drop_thr, k1 = (bits >> 16) >= drop_thr;
+            keep[e] = __builtin_amdgcn_ballot_w64(k0);
+            keep[e + 1] = __builtin_amdgcn_ballot_w64(k1);
+            s[e] = k0 ? s[e] : 0.f;
+            s[e + 1] = k1 ? s[e + 1] : 0.f;
+        }
+        if (keep_out) {                            // a backward follows: the 16 bits, element 0 at bit 15
+            unsigned packed = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) push_bit(packed, keep[e]);
+            keep_out[(key0 >> 5) * 64] = (unsigned short)packed;
         }
     }
 }
@@ -168,6 +191,7 @@ struct MhaFwdArgs {
     float* O; long ldo; float* LSE; const unsigned char* kpm;
     int Lq, Lk, H; float scale; unsigned drop_thr, drop_seed; float drop_scale;
     int nsplit; float* part_o; float* part_ml;
+    unsigned* keep_bits;      // dropout keep bits for the backward pass, or null (layout: attn_bits_words)
 };
 
 // (bx, head, b, nb): the workgroup's index along the (query tile, key range) axis, its head, clip and the clip count
@@ -198,6 +222,11 @@ __device__ __forceinline__ void mha_fwd_body(const MhaFwdArgs& A, int bx, int he
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    // this lane's 16-bit slot of the keep-bit words of its query (null: no backward follows, or a query past the end)
+    unsigned short* const keep_lane = A.keep_bits && qok
+        ? reinterpret_cast<unsigned short*>(A.keep_bits + ((long)b * H + head) * attn_bits_words(Lq, Lk) +
+                                            (long)(q >> 5) * ((Lk + 31) / 32) * 32 + (q & 31)) + h
+        : nullptr;
 
     const float* Kb = K + (long)b * Lk * ldk + head * DH;
     const float* Vb = V + (long)b * Lk * ldv + head * DH;
@@ -254,7 +283,7 @@ __device__ __forceinline__ void mha_fwd_body(const MhaFwdArgs& A, int bx, int he
                 mma(kf, qf, s);
             }
             // ---- mask, online softmax (per lane = per query)
-            softmax_block(mb || key0 + 32 > Lk, s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
+            softmax_block(mb || key0 + 32 > Lk, s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale, keep_lane);
             // ---- O^T += V^T P^T   (reduction slot e of half h is key acc_row(e,h): the S^T accumulator IS the operand)
             {
                 Frag<BF16> vf, pf;
@@ -323,7 +352,7 @@ __global__ __launch_bounds__(256, 3) void mha_fwd_pair_kernel(MhaFwdArgs A0, Mha
 __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
     const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
     float* __restrict__ O, long ldo, float* __restrict__ LSE, const unsigned char* __restrict__ kpm,
-    int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed, float drop_scale) {
+    int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed, float drop_scale, unsigned* keep_bits) {
     __shared__ __attribute__((aligned(16))) float lds[3 * 2 * 32 * KP];
     auto Ks = [&](int j) { return lds + (j % 3) * 2 * 32 * KP; };
     auto Vs = [&](int j) { return lds + (j % 3) * 2 * 32 * KP + 32 * KP; };
@@ -342,6 +371,10 @@ __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    unsigned short* const keep_lane = keep_bits && qok
+        ? reinterpret_cast<unsigned short*>(keep_bits + ((long)b * H + head) * attn_bits_words(Lq, Lk) +
+                                            (long)(q >> 5) * ((Lk + 31) / 32) * 32 + (q & 31)) + h
+        : nullptr;
 
     const unsigned char* mb = kpm ? kpm + (long)b * Lk : nullptr;
     const int n = (Lk + 31) / 32;
@@ -381,7 +414,7 @@ __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
     };
     auto softmax = [&](int j, f32x16& s) {
         const int key0 = j * 32;
-        softmax_block(mb || key0 + 32 > Lk, s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale);
+        softmax_block(mb || key0 + 32 > Lk, s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale, keep_lane);
     };
 
     fetch(0);
@@ -431,7 +464,8 @@ __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
 
 static int mha_fwd_impl(bool bf16, const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                         float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B, int Lq, int Lk,
-                        int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed, hipStream_t stream) {
+                        int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed, unsigned* drop_bits,
+                        hipStream_t stream) {
     SPOT_CHECK_ARG(q && k && v && out, "mha_fwd: null pointer");
     SPOT_CHECK_ARG(head_dim == DH, "mha_fwd: head_dim=%d unsupported (this build handles 32)", head_dim);
     SPOT_CHECK_ARG(B >= 0 && Lq > 0 && Lk > 0 && nhead > 0, "mha_fwd: bad shape B=%d Lq=%d Lk=%d heads=%d", B, Lq, Lk, nhead);
@@ -448,35 +482,40 @@ static int mha_fwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
         // the matrix work shrinks 16-fold: the loop is vector-bound and gains nothing from pairing matrix with vector phases
         dim3 grid((Lq + 127) / 128, nhead, B);
         mha_fwd_kernel<true><<<grid, 256, 0, stream>>>(MhaFwdArgs{q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk,
-                                                       nhead, scale, thr, drop_seed, dscale, 1, nullptr, nullptr});
+                                                       nhead, scale, thr, drop_seed, dscale, 1, nullptr, nullptr, drop_bits});
     } else if (Lq >= 512 && (long)((Lq + 255) / 256) * nhead * B >= 512) {
         // 256-query workgroups need enough of them to fill the chip; short query streams keep the 128-query kernel
         dim3 grid((Lq + 255) / 256, nhead, B);
         mha_fwd_pp_kernel<<<grid, 512, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk, nhead,
-                                                    scale, thr, drop_seed, dscale);
+                                                    scale, thr, drop_seed, dscale, drop_bits);
     } else {
         dim3 grid((Lq + 127) / 128, nhead, B);
         mha_fwd_kernel<false><<<grid, 256, 0, stream>>>(MhaFwdArgs{q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk,
-                                                        nhead, scale, thr, drop_seed, dscale, 1, nullptr, nullptr});
+                                                        nhead, scale, thr, drop_seed, dscale, 1, nullptr, nullptr, drop_bits});
     }
     SPOT_CHECK_LAUNCH("mha_fwd");
     return SPOT_OK;
 }
 
+extern "C" long spot_mha_drop_bits_words(int B, int nhead, int Lq, int Lk) {
+    if (B <= 0 || nhead <= 0 || Lq <= 0 || Lk <= 0) return 0;
+    return (long)B * nhead * ((long)((Lq + 31) / 32) * ((Lk + 31) / 32) * 32);
+}
+
 extern "C" int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                 float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B,
                                 int Lq, int Lk, int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed,
-                                hipStream_t stream) {
+                                unsigned* drop_bits, hipStream_t stream) {
     return mha_fwd_impl(false, q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, B, Lq, Lk, nhead, head_dim, scale,
-                        drop_p, drop_seed, stream);
+                        drop_p, drop_seed, drop_bits, stream);
 }
 
 extern "C" int spot_mha_fwd_bf16(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                  float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B,
                                  int Lq, int Lk, int nhead, int head_dim, float scale, float drop_p, unsigned drop_seed,
-                                 hipStream_t stream) {
+                                 unsigned* drop_bits, hipStream_t stream) {
     return mha_fwd_impl(true, q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, B, Lq, Lk, nhead, head_dim, scale,
-                        drop_p, drop_seed, stream);
+                        drop_p, drop_seed, drop_bits, stream);
 }
 
 // ===========================================================================
@@ -519,16 +558,18 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(const float* __restrict_
     }
 }
 
-// DROP: attention dropout active (drop_thr != 0); a template parameter so that the no-dropout loop carries none of it
-template <bool BF16, bool DROP>
+// DROP: 0 = no attention dropout (the loop carries none of it), 1 = the mask is regenerated from the pair hash,
+// 2 = the mask is read from the keep bits the forward pass wrote (two instructions per element instead of the hash)
+template <bool BF16, int DROP>
 __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
     const float* __restrict__ dO, long lddo, const float* __restrict__ LSE, const float* __restrict__ delta,
     const unsigned char* __restrict__ kpm, float* __restrict__ dQ, long lddq, float* __restrict__ dK, long lddk,
     float* __restrict__ dV, long lddv, int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed,
-    float drop_scale) {
-    // LDS: 2 x (Q tile, dO tile) [32][QP], 2 x (lse, delta) [32], K tile [128][QP], 2 x 4 x dS/dQ patch [32][QP]
-    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * QP + 4 * 32 + 128 * QP + 2 * 4 * 32 * QP];
+    float drop_scale, const unsigned* __restrict__ keep_bits) {
+    // LDS: 2 x (Q tile, dO tile) [32][QP], 2 x (lse, delta) [32], K tile [128][QP], 2 x 4 x dS/dQ patch [32][QP],
+    //      2 x keep-bit words [4 waves][32 queries]
+    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * QP + 4 * 32 + 128 * QP + 2 * 4 * 32 * QP + (DROP == 2 ? 2 * 128 : 0)];
     auto Qs = [&](int buf) { return lds + buf * 32 * QP; };
     auto Gs = [&](int buf) { return lds + (2 + buf) * 32 * QP; };
     auto Ls = [&](int buf) { return lds + 4 * 32 * QP + buf * 64; };
@@ -536,6 +577,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     float* Kt = lds + 4 * 32 * QP + 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     float* const patches = Kt + 128 * QP;       // [2 sets][4 waves][32][QP]
+    unsigned* const Ms = reinterpret_cast<unsigned*>(patches + 2 * 4 * 32 * QP);     // [2][4 waves][32 queries] (DROP == 2)
 
     const int head = blockIdx.y, b = blockIdx.z;
     const int key_w0 = blockIdx.x * 128 + wave * 32;
@@ -543,6 +585,11 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const float c = scale * 1.4426950408889634f;   // folded into the K fragment: scores come out in the log2 domain
     const unsigned ks = attn_stream_key(drop_seed, (unsigned)(b * H + head)) ^ (unsigned)(key & ~1);
     const unsigned half_shift = (key & 1) ? 0u : 16u, thr_hi = drop_thr << 16;
+    // keep bits: where this lane's key sits in a query's word (see attn_bits_words), and this workgroup's words
+    const unsigned keep_pos = 16u * ((l31 >> 2) & 1) + 15u - ((l31 & 3) + 4 * (l31 >> 3));
+    const int nkt = (Lk + 31) / 32;
+    const unsigned* Mb = DROP == 2 ? keep_bits + ((long)b * H + head) * attn_bits_words(Lq, Lk) : nullptr;
+    unsigned sm = 0;
 
     const float* Qb = Q + (long)b * Lq * ldq + head * DH;
     const float* Gb = dO + (long)b * Lq * lddo + head * DH;
@@ -580,12 +627,17 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
             const int qq = t * 32 + tid - 32;
             sl = qq < Lq ? (DROP ? Db[qq] : -Db[qq]) : 0.f;                  // without dropout dP starts at -delta
         }
+        if (DROP == 2 && tid >= 128) {          // word of (key tile 4 bx + w, query t * 32 + i), w = (tid - 128) / 32
+            const int kt = blockIdx.x * 4 + ((tid - 128) >> 5), qq = t * 32 + (tid & 31);
+            sm = kt < nkt && qq < Lq ? Mb[((long)t * nkt + kt) * 32 + (tid & 31)] : 0u;
+        }
     };
     auto stash = [&](int buf) {
         *reinterpret_cast<float4*>(Qs(buf) + (tid >> 3) * QP + ((tid & 7) << 2)) = sq;
         *reinterpret_cast<float4*>(Gs(buf) + (tid >> 3) * QP + ((tid & 7) << 2)) = sg;
         if (tid < 32) Ls(buf)[tid] = sl;
         else if (tid < 64) Ds(buf)[tid - 32] = sl;
+        if (DROP == 2 && tid >= 128) Ms[buf * 128 + tid - 128] = sm;
     };
     fetch(0);
     stash(0);
@@ -648,16 +700,33 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
             for (int e = 0; e < 16; ++e) s[e] = kdead ? 0.f : s[e];
         }
         if (DROP) {
-            const unsigned x0 = ks ^ ((unsigned)(t * 32 + 4 * h) << 16);     // query index sits in the high half
+            f32x16 ms;                                  // the mask times 1 / (1 - p): 0 or drop_scale per element
+            if (DROP == 2) {
+                const unsigned scale_bits = __float_as_uint(drop_scale);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const uint4 w4 = *reinterpret_cast<const uint4*>(Ms + cur * 128 + wave * 32 + 8 * g4 + 4 * h);
+                    const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
+                    // 0 or all ones from this key's bit of the query's word, then the scale or 0
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        ms[4 * g4 + i] = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)w[i], keep_pos, 1u) & scale_bits);
+                }
+            } else {
+                const unsigned x0 = ks ^ ((unsigned)(t * 32 + 4 * h) << 16);     // query index sits in the high half
                 // the pair hash of (query, key & ~1): an odd key reads its high half; an even key's low half is moved up,
                 // and the comparison runs on the upper 16 bits (the threshold's lower 16 are zero)
-                const float ms = (attn_mix(x0 ^ ((unsigned)acc_row(e, 0) << 16)) << half_shift) >= thr_hi ? drop_scale : 0.f;
-                const float p = s[e];
-                s[e] = p * ms;                              // dropped probabilities feed dV
-                dp[e] = p * (dp[e] * ms - dl[e]);           // dS = P (M dP_drop - delta)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    ms[e] = (attn_mix(x0 ^ ((unsigned)acc_row(e, 0) << 16)) << half_shift) >= thr_hi ? drop_scale : 0.f;
             }
+            // dropped probabilities feed dV; dS = P (M dP - delta) = (P M) dP - P delta, in packed operations
+            f32x16 dlv;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dlv[e] = dl[e];
+            const f32x16 pm = s * ms, pd = s * dlv;
+            dp = pm * dp - pd;
+            s = pm;
         } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) dp[e] *= s[e];
@@ -725,7 +794,7 @@ static int mha_bwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
                         const float* out, long ldo, const float* d_out, long lddo, const float* lse,
                         const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq, float* dk,
                         long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead, int head_dim, float scale,
-                        float drop_p, unsigned drop_seed, hipStream_t stream) {
+                        float drop_p, unsigned drop_seed, const unsigned* drop_bits, hipStream_t stream) {
     SPOT_CHECK_ARG(q && k && v && out && d_out && lse && delta_ws && dq && dk && dv, "mha_bwd: null pointer");
     SPOT_CHECK_ARG(head_dim == DH, "mha_bwd: head_dim=%d unsupported (this build handles 32)", head_dim);
     SPOT_CHECK_ARG(B >= 0 && Lq > 0 && Lk > 0 && nhead > 0, "mha_bwd: bad shape B=%d Lq=%d Lk=%d heads=%d", B, Lq, Lk, nhead);
@@ -746,13 +815,15 @@ static int mha_bwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
 #define SPOT_MHA_BWD(BF, DR)                                                                                                   \
     mha_bwd_kernel<BF, DR><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, d_out, lddo, lse, delta_ws, key_padding_mask, dq, \
                                                      lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale, thr, drop_seed,           \
-                                                     1.f / (1.f - drop_p))
+                                                     1.f / (1.f - drop_p), drop_bits)
     if (bf16) {
-        if (thr) SPOT_MHA_BWD(true, true);
-        else SPOT_MHA_BWD(true, false);
+        if (thr && drop_bits) SPOT_MHA_BWD(true, 2);
+        else if (thr) SPOT_MHA_BWD(true, 1);
+        else SPOT_MHA_BWD(true, 0);
     } else {
-        if (thr) SPOT_MHA_BWD(false, true);
-        else SPOT_MHA_BWD(false, false);
+        if (thr && drop_bits) SPOT_MHA_BWD(false, 2);
+        else if (thr) SPOT_MHA_BWD(false, 1);
+        else SPOT_MHA_BWD(false, 0);
     }
 #undef SPOT_MHA_BWD
     SPOT_CHECK_LAUNCH("mha_bwd");
@@ -763,18 +834,20 @@ extern "C" int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long l
                                 const float* out, long ldo, const float* d_out, long lddo, const float* lse,
                                 const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq,
                                 float* dk, long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead,
-                                int head_dim, float scale, float drop_p, unsigned drop_seed, hipStream_t stream) {
+                                int head_dim, float scale, float drop_p, unsigned drop_seed, const unsigned* drop_bits,
+                                hipStream_t stream) {
     return mha_bwd_impl(false, q, ldq, k, ldk, v, ldv, out, ldo, d_out, lddo, lse, key_padding_mask, delta_ws, dq, lddq,
-                        dk, lddk, dv, lddv, B, Lq, Lk, nhead, head_dim, scale, drop_p, drop_seed, stream);
+                        dk, lddk, dv, lddv, B, Lq, Lk, nhead, head_dim, scale, drop_p, drop_seed, drop_bits, stream);
 }
 
 extern "C" int spot_mha_bwd_bf16(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                                  const float* out, long ldo, const float* d_out, long lddo, const float* lse,
                                  const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq,
                                  float* dk, long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead,
-                                 int head_dim, float scale, float drop_p, unsigned drop_seed, hipStream_t stream) {
+                                 int head_dim, float scale, float drop_p, unsigned drop_seed, const unsigned* drop_bits,
+                                 hipStream_t stream) {
     return mha_bwd_impl(true, q, ldq, k, ldk, v, ldv, out, ldo, d_out, lddo, lse, key_padding_mask, delta_ws, dq, lddq,
-                        dk, lddk, dv, lddv, B, Lq, Lk, nhead, head_dim, scale, drop_p, drop_seed, stream);
+                        dk, lddk, dv, lddv, B, Lq, Lk, nhead, head_dim, scale, drop_p, drop_seed, drop_bits, stream);
 }
 
 

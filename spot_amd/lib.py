@@ -99,17 +99,17 @@ SIGNATURES = {
     "spot_maxpool3x3s2_bwd_f32": [vp, vp, vp, i64, i32, i32, vp],
     "spot_conv3x3_winograd_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "spot_conv3x3_winograd_wgrad_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
-    "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
+    "spot_mha_fwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp, vp],
     "spot_mha_fwd_splitk_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp] + [i32] * 6 + [f32, vp],
     "spot_mha_fwd_splitk_pair_f32": ([vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32] * 2) + [i32, i32, f32, vp],
     "spot_layernorm_fwd_pair_f32": [vp, vp, vp, vp, i64, f32, vp, vp, vp, vp, i64, f32, i32, vp],
     "spot_gemm_pair_f32": [vp, vp, vp],
     "spot_mha_fwd_splitk_noalloc_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp] + [i32] * 6 + [f32, vp],
     "spot_mha_bwd_f32": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64,
-                         i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
-    "spot_mha_fwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
+                         i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp, vp],
+    "spot_mha_fwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp, vp],
     "spot_mha_bwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64,
-                         i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp],
+                         i32, i32, i32, i32, i32, f32, f32, C.c_uint, vp, vp],
     "spot_mha_dropout_mask": [vp, i32, i32, i32, i32, f32, C.c_uint, vp],
     "spot_dropout_f32": [vp, vp, i64, i32, f32, C.c_uint, vp],
     "spot_layernorm_fwd_f32": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
@@ -147,6 +147,8 @@ def load():
     lib.spot_conv3x3_winograd_general_v_floats.argtypes = [i32] * 7
     lib.spot_mha_fwd_splitk_ws_floats.restype = i64
     lib.spot_mha_fwd_splitk_ws_floats.argtypes = [i32] * 4
+    lib.spot_mha_drop_bits_words.restype = i64
+    lib.spot_mha_drop_bits_words.argtypes = [i32] * 4
     lib.spot_transt_loss_ws_floats.restype = i64
     lib.spot_transt_loss_ws_floats.argtypes = []
     lib.spot_clip_grad_norm_ws_floats.restype = i64

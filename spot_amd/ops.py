@@ -1557,8 +1557,13 @@ def _mha_key_splits(B, Lq, Lk, nhead):
     return max(1, min((Lk + 63) // 64, 8, 384 // wgs))
 
 
+def mha_drop_bits(B, nhead, Lq, Lk, device):
+    """Buffer for the keep bits an attention forward with dropout hands to its backward (one bit per query and key)."""
+    return torch.empty((lib.load().spot_mha_drop_bits_words(B, nhead, Lq, Lk),), dtype=torch.int32, device=device)
+
+
 def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, out=None, drop_p=0.0, drop_seed=0,
-                 bf16=False):
+                 bf16=False, drop_bits=None):
     dev = q.device
     if out is None:
         out = torch.empty((B * Lq, nhead * dh), dtype=torch.float32, device=dev)
@@ -1570,7 +1575,7 @@ def mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, want_lse, ou
         return out, None
     lse = torch.empty((B, nhead, Lq), dtype=torch.float32, device=dev) if want_lse else None
     launch = lambda: lib.call("spot_mha_fwd_bf16" if bf16 else "spot_mha_fwd_f32", _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), out.stride(0), _p(lse),
-                              _p(kpm), B, Lq, Lk, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), drop_seed, _st())
+                              _p(kpm), B, Lq, Lk, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), drop_seed, _p(drop_bits), _st())
     if TIMER is not None and TIMER.wants("mha_fwd"):
         TIMER.run("mha_fwd Lq%d Lk%d B%d" % (Lq, Lk, B) if TIMER.shapes else "mha_fwd", 4.0 * B * nhead * Lq * Lk * dh, launch)
     else:
@@ -1675,11 +1680,13 @@ class MHAFn(_Fn):
         need_grad = _wants(ctx)
         sa = next_seed() if p_attn > 0 else 0
         so = next_seed() if p_out > 0 else 0
+        # with dropout the forward leaves the mask it drew as bits for the backward
+        keep = mha_drop_bits(B, nhead, Lq, Lk, dev) if need_grad and p_attn > 0 else None
         attn, lse = mha_core_fwd(q, ldq, k, ldk, v, ldv, B, Lq, Lk, nhead, dh, kpm, need_grad, drop_p=p_attn,
-                                 drop_seed=sa, bf16=bf16)
+                                 drop_seed=sa, bf16=bf16, drop_bits=keep)
         z = linear_fwd(attn, out_w, out_b, residual=xq2 if add_residual else None, drop_p=p_out, drop_seed=so)
         if need_grad:
-            ctx.save_for_backward(xq2, xkv2, pos_q, pos_k, in_w, out_w, qkv, kv, attn, lse, kpm)
+            ctx.save_for_backward(xq2, xkv2, pos_q, pos_k, in_w, out_w, qkv, kv, attn, lse, kpm, keep)
             ctx.dims = (B, Lq, Lk, Cn, nhead, dh, self_attn, bool(add_residual))
             ctx.drop = (p_attn, sa, p_out, so)
             ctx.bwd_entry = "spot_mha_bwd_bf16" if bf16 else "spot_mha_bwd_f32"
@@ -1689,7 +1696,7 @@ class MHAFn(_Fn):
 
     @staticmethod
     def backward(ctx, dz):
-        xq2, xkv2, pos_q, pos_k, in_w, out_w, qkv, kv, attn, lse, kpm = ctx.saved_tensors
+        xq2, xkv2, pos_q, pos_k, in_w, out_w, qkv, kv, attn, lse, kpm, keep = ctx.saved_tensors
         B, Lq, Lk, Cn, nhead, dh, self_attn, has_res = ctx.dims
         dev = dz.device
         p_attn, sa, p_out, so = ctx.drop
@@ -1710,7 +1717,7 @@ class MHAFn(_Fn):
                 ctx.bwd_entry, _p(qkv), 3 * Cn, _p(qkv[:, Cn:]), 3 * Cn, _p(qkv[:, 2 * Cn:]), 3 * Cn,
                 _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
                 _p(dqkv), 3 * Cn, _p(dqkv[:, Cn:]), 3 * Cn, _p(dqkv[:, 2 * Cn:]), 3 * Cn,
-                B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _st()))
+                B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _p(keep), _st()))
             dxq = linear_dgrad(dqkv, in_w, residual=dz2 if has_res else None)
             dxkv = None
             linear_wgrad(dqkv, xq2, out=d_in_w, accumulate=True, bias_out=d_in_b)
@@ -1724,7 +1731,7 @@ class MHAFn(_Fn):
                 ctx.bwd_entry, _p(qkv), Cn, _p(kv), 2 * Cn, _p(kv[:, Cn:]), 2 * Cn,
                 _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
                 _p(dq), Cn, _p(dkv), 2 * Cn, _p(dkv[:, Cn:]), 2 * Cn,
-                B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _st()))
+                B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _p(keep), _st()))
             dxq = linear_dgrad(dq, in_w[:Cn], residual=dz2 if has_res else None)
             dxkv = linear_dgrad(dkv, in_w[Cn:])
             linear_wgrad(dq, xq2, out=d_in_w[:Cn], accumulate=True, bias_out=d_in_b[:Cn])

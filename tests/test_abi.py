@@ -39,5 +39,5 @@ def test_argument_errors_are_reported_without_a_gpu():
     rc = l.spot_decode_teacher_f32(None, None, None, None, 0.4, 256, 256, None, None, None, None, 4, 1024, None)
     assert rc < 0
     assert b"null pointer" in l.spot_last_error()
-    rc = l.spot_mha_fwd_f32(1, 0, 1, 0, 1, 0, 1, 0, None, None, 1, 16, 16, 2, 64, 0.1, 0.0, 0, None)
+    rc = l.spot_mha_fwd_f32(1, 0, 1, 0, 1, 0, 1, 0, None, None, 1, 16, 16, 2, 64, 0.1, 0.0, 0, None, None)
     assert rc < 0 and b"head_dim" in l.spot_last_error()

@@ -346,7 +346,7 @@ def test_mha_core_fwd_bwd(ops, Lq, Lk):
     dog = G(do).view(-1, C)
     P = ops._p
     L.call("spot_mha_bwd_f32", P(qg), C, P(kg), C, P(vg), C, P(out), C, P(dog), C, P(lse), P(kp), P(delta),
-           P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), 0.0, 0, ops._st())
+           P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), 0.0, 0, None, ops._st())
     np.testing.assert_allclose(dq.view(B, Lq, C).cpu().numpy(), qc.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(dk.view(B, Lk, C).cpu().numpy(), kc.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(dv.view(B, Lk, C).cpu().numpy(), vc.grad.numpy(), rtol=2e-4, atol=2e-5)
@@ -381,7 +381,7 @@ def test_mha_core_bf16_products_track_fp32(ops, Lq, Lk):
     dog = G(do).view(-1, C)
     P = ops._p
     L.call("spot_mha_bwd_bf16", P(qg), C, P(kg), C, P(vg), C, P(out), C, P(dog), C, P(lse), P(kp), P(delta),
-           P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), 0.0, 0, ops._st())
+           P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), 0.0, 0, None, ops._st())
     for got, want in ((dq, qc.grad), (dk, kc.grad), (dv, vc.grad)):
         assert _cos(got.cpu(), want) > 0.999
         assert float((got.cpu().view_as(want) - want).abs().max()) <= 3e-2 * float(want.abs().max())
@@ -498,10 +498,50 @@ def test_mha_core_dropout_matches_explicit_mask(ops):
     delta = torch.empty((B, nh, Lq), device=DEV)
     P = ops._p
     L.call("spot_mha_bwd_f32", P(qg), C, P(kg), C, P(vg), C, P(out), C, P(G(do).view(-1, C)), C, P(lse), None, P(delta),
-           P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), p, seed, ops._st())
+           P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), p, seed, None, ops._st())
     np.testing.assert_allclose(dq.view(B, Lq, C).cpu().numpy(), qc.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(dk.view(B, Lk, C).cpu().numpy(), kc.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(dv.view(B, Lk, C).cpu().numpy(), vc.grad.numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("Lq,Lk,bf16", [(96, 160, False), (1024, 256, False), (256, 1024, False), (200, 77, False),
+                                        (160, 96, True)])
+def test_mha_keep_bits_from_the_forward_give_the_backward_of_the_regenerated_mask(ops, Lq, Lk, bf16):
+    """A forward with dropout that also writes its keep bits returns the same output, the bits are the byte mask
+    (query-tile / key-tile words in the forward lanes' order), and a backward that reads them equals the backward that
+    regenerates the mask from the seed: dK and dV bit for bit, dQ up to the order of its atomic adds."""
+    from spot_amd import lib as L
+    B, nh, dh, p, seed = (2, 4, 32, 0.2, 977) if Lq * Lk < 200000 else (8, 8, 32, 0.1, 31)
+    C = nh * dh
+    q, k, v = (G(det_input(n, (B * L_, C), 5, -2, 2)) for n, L_ in (("q", Lq), ("k", Lk), ("v", Lk)))
+    do = G(det_input("do", (B * Lq, C), 6, -1, 1))
+    out0, lse0 = ops.mha_core_fwd(q, C, k, C, v, C, B, Lq, Lk, nh, dh, None, True, drop_p=p, drop_seed=seed, bf16=bf16)
+    keep = ops.mha_drop_bits(B, nh, Lq, Lk, DEV)
+    keep.fill_(-1 if Lq % 2 else 0)                  # whatever the buffer held before must not matter
+    out1, lse1 = ops.mha_core_fwd(q, C, k, C, v, C, B, Lq, Lk, nh, dh, None, True, drop_p=p, drop_seed=seed, bf16=bf16,
+                                  drop_bits=keep)
+    assert torch.equal(out0, out1) and torch.equal(lse0, lse1)
+    # the words against the byte mask
+    mask = torch.empty((B, nh, Lq, Lk), dtype=torch.uint8, device=DEV)
+    L.call("spot_mha_dropout_mask", ops._p(mask), B, nh, Lq, Lk, p, seed, ops._st())
+    nqt, nkt = (Lq + 31) // 32, (Lk + 31) // 32
+    words = keep.view(B, nh, nqt, nkt, 32).cpu().numpy().astype(np.uint32)
+    r = np.arange(32)
+    pos = 16 * ((r >> 2) & 1) + 15 - ((r & 3) + 4 * (r >> 3))          # bit of key r (within its tile) in a query's word
+    got = ((words[..., None] >> pos.astype(np.uint32)) & 1).astype(np.uint8)      # [B, nh, nqt, nkt, 32 q, 32 keys]
+    got = got.transpose(0, 1, 2, 4, 3, 5).reshape(B, nh, nqt * 32, nkt * 32)[:, :, :Lq, :Lk]
+    assert np.array_equal(got, mask.cpu().numpy())
+    P = ops._p
+    entry = "spot_mha_bwd_bf16" if bf16 else "spot_mha_bwd_f32"
+    res = []
+    for bits in (None, keep):
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty((B, nh, Lq), device=DEV)
+        L.call(entry, P(q), C, P(k), C, P(v), C, P(out1), C, P(do), C, P(lse1), None, P(delta),
+               P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, nh, dh, 1.0 / math.sqrt(dh), p, seed, P(bits), ops._st())
+        res.append((dq, dk, dv))
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-5 * float(res[0][0].abs().max())
 
 
 def test_ffn_dropout_forward_backward_vs_explicit_masks(ops):

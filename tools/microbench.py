@@ -158,8 +158,10 @@ def bench_mha(shapes=((1024, 1024), (256, 256), (256, 1024), (1024, 256)), iters
     for Lq, Lk in shapes:
         q, k, v = r(B * Lq, C), r(B * Lk, C), r(B * Lk, C)
         out, lse = ops.mha_core_fwd(q, C, k, C, v, C, B, Lq, Lk, H, dh, None, True)
+        # as in training: with dropout the forward writes the keep bits its backward reads
+        keep = ops.mha_drop_bits(B, H, Lq, Lk, "cuda") if pd > 0 and os.environ.get("SPOT_MB_KEEP_BITS", "1") == "1" else None
         t = timeit(lambda: ops.mha_core_fwd(q, C, k, C, v, C, B, Lq, Lk, H, dh, None, True, out=out, drop_p=pd,
-                                            drop_seed=7, bf16=bf16), iters)
+                                            drop_seed=7, bf16=bf16, drop_bits=keep), iters)
         fl = 4.0 * B * H * Lq * Lk * dh
         do = r(B * Lq, C)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -168,7 +170,7 @@ def bench_mha(shapes=((1024, 1024), (256, 256), (256, 1024), (1024, 256)), iters
 
         def bwd():
             lib.call("spot_mha_bwd_bf16" if bf16 else "spot_mha_bwd_f32", P(q), C, P(k), C, P(v), C, P(out), C, P(do), C, P(lse), None, P(delta),
-                     P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, H, dh, 1.0 / math.sqrt(dh), pd, 7, ops._st())
+                     P(dq), C, P(dk), C, P(dv), C, B, Lq, Lk, H, dh, 1.0 / math.sqrt(dh), pd, 7, P(keep), ops._st())
         tb = timeit(bwd, iters)
         print("Lq=%4d Lk=%4d  fwd %8.1f us %6.1f TF | bwd %8.1f us %6.1f TF" %
               (Lq, Lk, t * 1e6, fl / t / 1e12, tb * 1e6, 2.5 * fl / tb / 1e12))
