@@ -28,7 +28,7 @@ def test_binding_covers_header_and_version():
     assert l.spot_version() == 100
     bound = set(lib.SIGNATURES) | {"spot_version", "spot_last_error", "spot_layernorm_bwd_ws_floats", "spot_batchnorm_ws_floats",
                                         "spot_conv3x3_winograd_ws_floats", "spot_conv3x3_winograd_wgrad_ws_floats",
-                                        "spot_deform_col2im_ws_floats", "spot_clip_grad_norm_ws_floats", "spot_transt_loss_ws_floats", "spot_mha_fwd_splitk_ws_floats", "spot_conv3x3_winograd_general_ws_floats",
+                                        "spot_deform_col2im_ws_floats", "spot_clip_grad_norm_ws_floats", "spot_transt_loss_ws_floats", "spot_mha_fwd_splitk_ws_floats", "spot_mha_drop_bits_words", "spot_conv3x3_winograd_general_ws_floats",
                                         "spot_conv3x3_winograd_general_v_floats"}
     assert bound == set(declared_symbols())
 
