@@ -66,6 +66,9 @@ def bench_gemm():
                   ("wgrad proj     ", 256, 256, M, True, True, dict(splitk=True)),
                   ("wgrad in-proj  ", 768, 256, M, True, True, dict(splitk=True))]
     cases.append(("fwd  input_proj", 1024, 256, 1024, True, False, dict(batch=B)))
+    # the square problem GEMM kernels are usually quoted on, in the two common layouts
+    cases.append(("square nt      ", 4096, 4096, 4096, False, False, {}))
+    cases.append(("square nn      ", 4096, 4096, 4096, False, True, {}))
     for name, M, N, K, ta, tb, opt in cases:
         batch = opt.get("batch", 1)
         A = r(batch, K, M) if ta else r(batch, M, K)
