@@ -389,8 +389,9 @@ int spot_mha_fwd_splitk_noalloc_f32(const float* q, long ldq, const float* k, lo
                                     float* out, long ldo, const unsigned char* key_padding_mask, int nsplit, int B,
                                     int Lq, int Lk, int nhead, int head_dim, float scale, hipStream_t stream);
 
-/* Gradient of spot_mha_fwd_f32 w.r.t. q, k, v given d_out.  delta_ws: workspace [B,nhead,Lq] floats.
- * dq is accumulated with atomic adds and is cleared by this call. */
+/* Gradient of spot_mha_fwd_f32 w.r.t. q, k, v given d_out.  delta_ws: no longer read or written (the row sums of
+ * out * d_out are taken inside the kernel); may be NULL.  dq is accumulated with atomic adds and is cleared by this
+ * call. */
 int spot_mha_bwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                      const float* out, long ldo, const float* d_out, long lddo, const float* lse,
                      const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq,

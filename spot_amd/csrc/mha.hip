@@ -534,28 +534,13 @@ namespace {
 
 constexpr int QP = DH + 4;   // padded LDS row
 
-__global__ __launch_bounds__(256) void mha_delta_kernel(const float* __restrict__ O, long ldo,
-                                                        const float* __restrict__ dO, long lddo,
-                                                        float* __restrict__ delta, float* __restrict__ dQ, long lddq,
-                                                        int Lq, int H, long total) {
-    // one 8-lane group per (b, q, head): 8 x float4 = 32 channels.  The same threads clear the head's dQ row,
-    // which the backward kernel accumulates into atomically.
-    const long gidx = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
-    const int part = threadIdx.x & 7;
-    if (gidx >= total) return;
-    const int head = (int)(gidx % H);
-    const long bq = gidx / H;           // b*Lq + q
-    const float4 a = *reinterpret_cast<const float4*>(O + bq * ldo + head * DH + 4 * part);
-    const float4 g = *reinterpret_cast<const float4*>(dO + bq * lddo + head * DH + 4 * part);
-    *reinterpret_cast<float4*>(dQ + bq * lddq + head * DH + 4 * part) = make_float4(0.f, 0.f, 0.f, 0.f);
-    float s = (a.x * g.x + a.y * g.y) + (a.z * g.z + a.w * g.w);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);
-    if (part == 0) {
-        const long b = bq / Lq, q = bq % Lq;
-        delta[(b * H + head) * Lq + q] = s;
-    }
+__global__ __launch_bounds__(256) void mha_clear_dq_kernel(float* __restrict__ dQ, long lddq, int width4, long rows) {
+    // dQ is accumulated with atomic adds: its [rows, 4 * width4] window (row stride lddq) starts at zero
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * width4) return;
+    const long r = i / width4;
+    const int c4 = (int)(i % width4);
+    *reinterpret_cast<float4*>(dQ + r * lddq + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // DROP: 0 = no attention dropout (the loop carries none of it), 1 = the mask is regenerated from the pair hash,
@@ -563,7 +548,7 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(const float* __restrict_
 template <bool BF16, int DROP>
 __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
-    const float* __restrict__ dO, long lddo, const float* __restrict__ LSE, const float* __restrict__ delta,
+    const float* __restrict__ O, long ldo, const float* __restrict__ dO, long lddo, const float* __restrict__ LSE,
     const unsigned char* __restrict__ kpm, float* __restrict__ dQ, long lddq, float* __restrict__ dK, long lddk,
     float* __restrict__ dV, long lddv, int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed,
     float drop_scale, const unsigned* __restrict__ keep_bits) {
@@ -593,8 +578,8 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
 
     const float* Qb = Q + (long)b * Lq * ldq + head * DH;
     const float* Gb = dO + (long)b * Lq * lddo + head * DH;
+    const float* Ob = O + (long)b * Lq * ldo + head * DH;
     const float* Lb = LSE + ((long)b * H + head) * Lq;
-    const float* Db = delta + ((long)b * H + head) * Lq;
 
     // K tile of the workgroup into LDS (zero rows past Lk); V fragment straight to registers
 #pragma unroll
@@ -609,23 +594,22 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const bool kvalid = key < Lk;
     const bool kdead = !kvalid || (kpm && kpm[(long)b * Lk + key]);
     load_frag(vf, V + ((long)b * Lk + (kvalid ? key : 0)) * ldv + head * DH + 16 * h, kvalid ? 1.f : 0.f);
-    float4 sq, sg;
+    float4 sq, sg, so;
     float sl = 0.f;
     auto fetch = [&](int t) {
         const int qr = t * 32 + (tid >> 3), d4 = (tid & 7) << 2;
         if (qr < Lq) {
             sq = *reinterpret_cast<const float4*>(Qb + (long)qr * ldq + d4);
             sg = *reinterpret_cast<const float4*>(Gb + (long)qr * lddo + d4);
+            so = *reinterpret_cast<const float4*>(Ob + (long)qr * ldo + d4);
         } else {
             sq = make_float4(0.f, 0.f, 0.f, 0.f);
             sg = sq;
+            so = sq;
         }
         if (tid < 32) {
             const int qq = t * 32 + tid;
             sl = qq < Lq ? -(Lb[qq] * 1.4426950408889634f) : -INFINITY;      // the score accumulator starts at -LSE
-        } else if (tid < 64) {
-            const int qq = t * 32 + tid - 32;
-            sl = qq < Lq ? (DROP ? Db[qq] : -Db[qq]) : 0.f;                  // without dropout dP starts at -delta
         }
         if (DROP == 2 && tid >= 128) {          // word of (key tile 4 bx + w, query t * 32 + i), w = (tid - 128) / 32
             const int kt = blockIdx.x * 4 + ((tid - 128) >> 5), qq = t * 32 + (tid & 31);
@@ -636,7 +620,13 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
         *reinterpret_cast<float4*>(Qs(buf) + (tid >> 3) * QP + ((tid & 7) << 2)) = sq;
         *reinterpret_cast<float4*>(Gs(buf) + (tid >> 3) * QP + ((tid & 7) << 2)) = sg;
         if (tid < 32) Ls(buf)[tid] = sl;
-        else if (tid < 64) Ds(buf)[tid - 32] = sl;
+        // delta[q] = sum_c O[q][c] dO[q][c] of this head: the eight lanes that hold a query row's 32 channels add up
+        // (every workgroup of the (clip, head) computes the same value in the same order)
+        float dsum = (so.x * sg.x + so.y * sg.y) + (so.z * sg.z + so.w * sg.w);
+        dsum += __shfl_xor(dsum, 1);
+        dsum += __shfl_xor(dsum, 2);
+        dsum += __shfl_xor(dsum, 4);
+        if ((tid & 7) == 0) Ds(buf)[tid >> 3] = DROP ? dsum : -dsum;          // without dropout dP starts at -delta
         if (DROP == 2 && tid >= 128) Ms[buf * 128 + tid - 128] = sm;
     };
     fetch(0);
@@ -795,7 +785,8 @@ static int mha_bwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
                         const unsigned char* key_padding_mask, float* delta_ws, float* dq, long lddq, float* dk,
                         long lddk, float* dv, long lddv, int B, int Lq, int Lk, int nhead, int head_dim, float scale,
                         float drop_p, unsigned drop_seed, const unsigned* drop_bits, hipStream_t stream) {
-    SPOT_CHECK_ARG(q && k && v && out && d_out && lse && delta_ws && dq && dk && dv, "mha_bwd: null pointer");
+    (void)delta_ws;      // kept in the signature; the kernel computes delta itself
+    SPOT_CHECK_ARG(q && k && v && out && d_out && lse && dq && dk && dv, "mha_bwd: null pointer");
     SPOT_CHECK_ARG(head_dim == DH, "mha_bwd: head_dim=%d unsupported (this build handles 32)", head_dim);
     SPOT_CHECK_ARG(B >= 0 && Lq > 0 && Lk > 0 && nhead > 0, "mha_bwd: bad shape B=%d Lq=%d Lk=%d heads=%d", B, Lq, Lk, nhead);
     SPOT_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && lddo % 4 == 0 &&
@@ -805,15 +796,15 @@ static int mha_bwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
     SPOT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mha_bwd: drop_p=%f outside [0,1)", drop_p);
     SPOT_CHECK_ARG(drop_p == 0.f || (Lq <= 65536 && Lk <= 65536), "mha_bwd: dropout needs Lq, Lk <= 65536");
     if (B == 0) return SPOT_OK;
-    // dQ is accumulated atomically: the delta pass clears its [B*Lq, nhead*32] window on the way
-    const long total = (long)B * Lq * nhead;
-    mha_delta_kernel<<<(int)((total * 8 + 255) / 256), 256, 0, stream>>>(out, ldo, d_out, lddo, delta_ws, dq, lddq, Lq,
-                                                                          nhead, total);
-    SPOT_CHECK_LAUNCH("mha_bwd(delta)");
+    // dQ is accumulated atomically: its [B*Lq, nhead*32] window is cleared first
+    SPOT_CHECK_ARG(lddq % 4 == 0 && ((uintptr_t)dq & 15) == 0, "mha_bwd: dq must be 16-byte aligned with a row stride that is a multiple of 4");
+    const long rows = (long)B * Lq, cells = rows * (nhead * DH / 4);
+    mha_clear_dq_kernel<<<(int)((cells + 255) / 256), 256, 0, stream>>>(dq, lddq, nhead * DH / 4, rows);
+    SPOT_CHECK_LAUNCH("mha_bwd(clear)");
     dim3 grid((Lk + 127) / 128, nhead, B);
     const unsigned thr = attn_threshold(drop_p);
 #define SPOT_MHA_BWD(BF, DR)                                                                                                   \
-    mha_bwd_kernel<BF, DR><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, d_out, lddo, lse, delta_ws, key_padding_mask, dq, \
+    mha_bwd_kernel<BF, DR><<<grid, 256, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, d_out, lddo, lse, key_padding_mask, dq, \
                                                      lddq, dk, lddk, dv, lddv, Lq, Lk, nhead, scale, thr, drop_seed,           \
                                                      1.f / (1.f - drop_p), drop_bits)
     if (bf16) {
