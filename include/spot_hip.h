@@ -426,11 +426,16 @@ int spot_layernorm_fwd_pair_f32(const float* x0, const float* gamma0, const floa
                                 const float* x1, const float* gamma1, const float* beta1, float* y1, long rows1, float eps1,
                                 int C, hipStream_t stream);
 /* dx, dgamma, dbeta (the latter two overwritten, or added to when accumulate != 0; either may be NULL).  ws: workspace of
- * spot_layernorm_bwd_ws_floats(rows, C) floats holding per-workgroup partial sums. */
+ * spot_layernorm_bwd_ws_floats(rows, C) floats holding per-workgroup partial sums.
+ * dx_dropped (NULL to skip): a second copy of dx behind the mask spot_dropout_f32(dx, drop_p, drop_seed) would apply -
+ * the gradient behind the output dropout of the attention / feed-forward block whose result this LayerNorm normalised
+ * (nn.Dropout at transt_fusion.py:149,152,214,232,241), which that block's backward would otherwise make with a pass
+ * of its own over dx. */
 long spot_layernorm_bwd_ws_floats(long rows, int C);
 int spot_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd,
                            const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws, long rows,
-                           int C, int accumulate, hipStream_t stream);
+                           int C, int accumulate, float* dx_dropped, float drop_p, unsigned drop_seed,
+                           hipStream_t stream);
 
 /* Gradients of the two calls above.  d_out [planes, hx-hz+1, wx-wz+1]; dx / dkernel may be NULL to skip. */
 int spot_xcorr_depthwise_bwd_f32(const float* x, const float* kernel, const float* d_out, float* dx,

@@ -75,6 +75,8 @@ class ParamArena:
         if self.grad_flat is not None:
             self.grad_flat.zero_()
         self._owed.clear()
+        from . import ops
+        ops._DROPPED.clear()        # masked gradients of a backward pass that never asked for them
 
     def signature(self):
         return [(k, tuple(t.shape)) for k, t in self.f32], [k for k, _ in self.i64]

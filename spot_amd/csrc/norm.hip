@@ -77,10 +77,15 @@ __global__ __launch_bounds__(256) void ln_fwd_pair_kernel(const float* __restric
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;  dgamma = sum dy * xhat;  dbeta = sum dy
+// dxd (optional): a second copy of dx behind the dropout mask of (drop_seed, row, column) that a GEMM epilogue applied
+// to the block that produced this LayerNorm's input: the gradient that block's weight and input products start from,
+// written here instead of by a pass of its own over dx.
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dx,
-                                                     float* __restrict__ partial, long rows, int C) {
+                                                     float* __restrict__ partial, long rows, int C,
+                                                     float* __restrict__ dxd, unsigned drop_thr, unsigned drop_seed,
+                                                     float drop_scale) {
     __shared__ float4 red[2][4][64 * MAXV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
@@ -116,12 +121,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
         const float c1 = wave_sum(s1) / C, c2 = wave_sum(s2) / C;
         float4* op = reinterpret_cast<float4*>(dx + row * C);
+        float4* od = dxd ? reinterpret_cast<float4*>(dxd + row * C) : nullptr;
+        const unsigned rk = spot_row_key(drop_seed, (unsigned)row);
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int idx = lane + 64 * i;
-            if (idx < nv)
-                op[idx] = make_float4(rs * (g[i].x - c1 - xh[i].x * c2), rs * (g[i].y - c1 - xh[i].y * c2),
-                                      rs * (g[i].z - c1 - xh[i].z * c2), rs * (g[i].w - c1 - xh[i].w * c2));
+            if (idx < nv) {
+                const float4 v = make_float4(rs * (g[i].x - c1 - xh[i].x * c2), rs * (g[i].y - c1 - xh[i].y * c2),
+                                             rs * (g[i].z - c1 - xh[i].z * c2), rs * (g[i].w - c1 - xh[i].w * c2));
+                op[idx] = v;
+                if (od) {
+                    const unsigned n = 4u * idx;
+                    od[idx] = make_float4(spot_keep(rk, n, drop_thr) ? v.x * drop_scale : 0.f,
+                                          spot_keep(rk, n + 1, drop_thr) ? v.y * drop_scale : 0.f,
+                                          spot_keep(rk, n + 2, drop_thr) ? v.z * drop_scale : 0.f,
+                                          spot_keep(rk, n + 3, drop_thr) ? v.w * drop_scale : 0.f);
+                }
+            }
         }
     }
     if (!partial) return;
@@ -291,7 +307,8 @@ extern "C" long spot_layernorm_bwd_ws_floats(long rows, int C) { return (long)ln
 
 extern "C" int spot_layernorm_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd,
                                       const float* gamma, float* dx, float* dgamma, float* dbeta, float* ws,
-                                      long rows, int C, int accumulate, hipStream_t stream) {
+                                      long rows, int C, int accumulate, float* dx_dropped, float drop_p, unsigned drop_seed,
+                                      hipStream_t stream) {
     SPOT_CHECK_ARG(rows >= 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXV, "layernorm_bwd: C=%d must be a multiple of 4, <= %d",
                    C, 256 * MAXV);
     if (rows == 0) {
@@ -306,7 +323,11 @@ extern "C" int spot_layernorm_bwd_f32(const float* dy, const float* x, const flo
                    "layernorm_bwd: buffers must be 16-byte aligned");
     const int grid = ln_bwd_grid(rows);
     const bool want = dgamma || dbeta;
-    ln_bwd_kernel<<<grid, 256, 0, stream>>>(dy, x, mean, rstd, gamma, dx, want ? ws : nullptr, rows, C);
+    SPOT_CHECK_ARG(!dx_dropped || (drop_p > 0.f && drop_p < 1.f && rows < (1L << 32) && ((uintptr_t)dx_dropped & 15) == 0),
+                   "layernorm_bwd: the dropped copy needs 0 < drop_p < 1, fewer than 2^32 rows and a 16-byte aligned buffer");
+    ln_bwd_kernel<<<grid, 256, 0, stream>>>(dy, x, mean, rstd, gamma, dx, want ? ws : nullptr, rows, C, dx_dropped,
+                                            dx_dropped ? spot_drop_threshold(drop_p) : 0u, drop_seed,
+                                            dx_dropped ? 1.f / (1.f - drop_p) : 1.f);
     SPOT_CHECK_LAUNCH("layernorm_bwd");
     if (want) {
         if (!accumulate) {

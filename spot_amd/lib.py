@@ -113,7 +113,7 @@ SIGNATURES = {
     "spot_mha_dropout_mask": [vp, i32, i32, i32, i32, f32, C.c_uint, vp],
     "spot_dropout_f32": [vp, vp, i64, i32, f32, C.c_uint, vp],
     "spot_layernorm_fwd_f32": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
-    "spot_layernorm_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+    "spot_layernorm_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, f32, C.c_uint, vp],
 }
 
 _lib = None

@@ -610,6 +610,40 @@ def dropout_apply(x2, p, seed):
     return out
 
 
+# The gradient behind a block's output dropout, made by the LayerNorm that follows the block.  An attention or
+# feed-forward block ends in  z = x + dropout(y);  its backward starts from  dropout_mask * dz,  and dz is what the
+# backward of the LayerNorm applied to z returns.  The block notes (address of z, p, seed) when it has run; a LayerNorm
+# called on exactly that tensor asks its backward kernel for the masked copy as a second output and files it under the
+# address of the gradient it returns; the block's backward picks it up if the gradient it receives is that very
+# tensor, unmodified (address, version and mask parameters match), and otherwise masks the gradient itself.
+_OUT_DROP = None
+_DROPPED = {}
+
+
+def _note_out_drop(z, p, seed, wanted):
+    """Called by a block's forward with its result z, its output dropout and whether a backward will follow."""
+    global _OUT_DROP
+    _OUT_DROP = (z.data_ptr(), float(p), int(seed)) if (p > 0 and wanted and z.is_cuda) else None
+
+
+def _out_drop_of(x):
+    """(p, seed) of the output dropout of the block that produced x, if x is the latest such block's result."""
+    global _OUT_DROP
+    hint, _OUT_DROP = _OUT_DROP, None
+    if hint is not None and hint[0] == x.data_ptr():
+        return hint[1], hint[2]
+    return 0.0, 0
+
+
+def _dropped_grad(dz2, p, seed):
+    """mask(seed) * dz2 / (1 - p): from the LayerNorm backward that produced dz2, else by a pass over dz2."""
+    hit = _DROPPED.pop(dz2.data_ptr(), None) if p > 0 else None
+    if (hit is not None and hit[2] == dz2._version and hit[3] == float(p) and hit[4] == int(seed)
+            and hit[1].shape == dz2.shape):
+        return hit[1]
+    return dropout_apply(dz2, p, seed)
+
+
 def linear_dgrad(dy2, W, mask=None, out=None, accumulate=False, residual=None, alpha=1.0):
     """dx[M,K] = dy2[M,N] W[N,K]  (optionally zeroed where mask <= 0, plus residual, or added into out)."""
     M, N = dy2.shape
@@ -795,6 +829,7 @@ class FFNFn(_Fn):
         ctx.drop = (p, s2)
         ctx.params = (W1, b1, W2, b2)
         _sink_expect(*ctx.params)
+        _note_out_drop(z, p, s2, _wants(ctx))
         return z.view_as(x)
 
     @staticmethod
@@ -802,7 +837,7 @@ class FFNFn(_Fn):
         x2, h, W1, W2 = ctx.saved_tensors
         p, s2 = ctx.drop
         dz2 = _view2d(dz.contiguous())
-        dzd = dropout_apply(dz2, p, s2)                      # gradient behind the output dropout
+        dzd = _dropped_grad(dz2, p, s2)                      # gradient behind the output dropout
         # h > 0 <=> relu passed and the hidden mask kept: one epilogue test, scaled by 1/(1-p)
         dh = linear_dgrad(dzd, W2, mask=h, alpha=1.0 / (1.0 - p))
         dx = linear_dgrad(dh, W1, residual=dz2)              # FFN path + residual path in one epilogue
@@ -821,11 +856,12 @@ class FFNFn(_Fn):
 # ---------------------------------------------------------------------------
 class LayerNormFn(_Fn):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, drop_p=0.0, drop_seed=0):
         x2 = _view2d(x.contiguous())
         rows, Cn = x2.shape
         y = torch.empty_like(x2)
         need = _wants(ctx)              # the row statistics are kept for backward only
+        ctx.out_drop = (drop_p, drop_seed)      # output dropout of the block that produced x (see _dropped_grad)
         mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if need else None
         rstd = torch.empty((rows,), dtype=torch.float32, device=x.device) if need else None
         lib.call("spot_layernorm_fwd_f32", _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, Cn,
@@ -849,16 +885,21 @@ class LayerNormFn(_Fn):
         dg = sg if direct else torch.empty_like(gamma)
         db = sb if direct else torch.empty_like(gamma)
         ws = torch.empty((lib.load().spot_layernorm_bwd_ws_floats(rows, Cn),), dtype=torch.float32, device=dy.device)
+        dp, dseed = ctx.out_drop
+        dxd = torch.empty_like(x2) if (dp > 0 and ctx.needs_input_grad[0]) else None
         lib.call("spot_layernorm_bwd_f32", _p(dy2), _p(x2), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dg), _p(db),
-                 _p(ws), rows, Cn, int(direct), _st())
+                 _p(ws), rows, Cn, int(direct), _p(dxd), float(dp), int(dseed), _st())
+        if dxd is not None:
+            _DROPPED[dx.data_ptr()] = (dx, dxd, dx._version, float(dp), int(dseed))
         if direct:
             _sink_done(pg, pb)
-            return dx.view_as(dy), None, None, None
-        return dx.view_as(dy), dg, db, None
+            return dx.view_as(dy), None, None, None, None, None
+        return dx.view_as(dy), dg, db, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):
-    return LayerNormFn.apply(x, gamma, beta, eps)
+    dp, dseed = _out_drop_of(x) if torch.is_grad_enabled() else (0.0, 0)
+    return LayerNormFn.apply(x, gamma, beta, eps, dp, dseed)
 
 
 def layer_norm_infer(x, gamma, beta, eps=1e-5):
@@ -1692,6 +1733,7 @@ class MHAFn(_Fn):
             ctx.bwd_entry = "spot_mha_bwd_bf16" if bf16 else "spot_mha_bwd_f32"
             ctx.params = (in_w, in_b, out_w, out_b)
             _sink_expect(*ctx.params)
+        _note_out_drop(z, p_out, so, need_grad)
         return z.view(B, Lq, Cn)
 
     @staticmethod
@@ -1701,7 +1743,7 @@ class MHAFn(_Fn):
         dev = dz.device
         p_attn, sa, p_out, so = ctx.drop
         dz2 = _view2d(dz.contiguous())
-        dzd = dropout_apply(dz2, p_out, so)                  # gradient behind the output dropout
+        dzd = _dropped_grad(dz2, p_out, so)                  # gradient behind the output dropout
         dattn = linear_dgrad(dzd, out_w)
         p_in_w, p_in_b, p_out_w, p_out_b = ctx.params
         sinks = [_sink(t) for t in ctx.params]

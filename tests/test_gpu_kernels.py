@@ -593,6 +593,43 @@ def test_fusion_layer_train_mode_dropout_is_reproducible_and_unbiased(ops):
     assert (r1[1] - e2).abs().mean().item() < 0.5 * e2.abs().mean().item()
 
 
+def test_layernorm_backward_hands_the_masked_gradient_to_the_block_before_it(ops, monkeypatch):
+    """The gradient behind a block's output dropout comes out of the following LayerNorm's backward kernel as a second
+    output; the block's backward uses it instead of a pass of its own.  Same gradients bit for bit either way, and the
+    stand-alone dropout pass is not launched when the hand-over works."""
+    from spot_amd.fusion import FeatureFusionLayer
+    d, nh, ff, B, Lt, Ls = 64, 2, 128, 2, 32, 96
+    layer = _load_det(FeatureFusionLayer(d, nh, ff, 0.1), 21).train()
+    a = lambda n, L_: G(det_input(n, (B, L_, d), 21, -1, 1))
+    s1, s2, p1, p2 = a("s1", Lt), a("s2", Ls), a("p1", Lt)[0], a("p2", Ls)[0]
+    calls = []
+    real = ops.dropout_apply
+    monkeypatch.setattr(ops, "dropout_apply", lambda x2, p, seed: (calls.append(p), real(x2, p, seed))[1])
+
+    def run(hand_over):
+        ops.manual_seed(11)
+        for q in layer.parameters():
+            q.grad = None
+        x1, x2 = s1.clone().requires_grad_(), s2.clone().requires_grad_()
+        o1, o2 = layer(x1, x2, None, None, p1, p2)
+        if not hand_over:
+            monkeypatch.setattr(ops, "_dropped_grad", lambda dz2, p, seed: ops.dropout_apply(dz2, p, seed))
+        del calls[:]
+        (o1.square().sum() + o2.sum()).backward()
+        n = len(calls)
+        monkeypatch.undo()
+        monkeypatch.setattr(ops, "dropout_apply", lambda x2, p, seed: (calls.append(p), real(x2, p, seed))[1])
+        return [x1.grad, x2.grad] + [q.grad.clone() for q in layer.parameters()], n
+
+    with_it, n_with = run(True)
+    assert not ops._DROPPED                      # every masked copy was picked up
+    without, n_without = run(False)
+    ops._DROPPED.clear()                         # (the copies nobody asked for; a training step clears them too)
+    assert n_without >= 6 and n_with == 0, (n_with, n_without)
+    for u, w in zip(with_it, without):
+        assert torch.equal(u, w)
+
+
 def test_xcorr_backward_golden(ops, golden):
     g = golden("g12_xcorr")
     for tag in ("ocean255", "cfg5"):

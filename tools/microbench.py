@@ -215,7 +215,7 @@ def bench_norm():
     print("ln fwd  %7.1f us %7.1f GB/s" % (t * 1e6, 2 * x.numel() * 4 / t / 1e9))
     dx, dg, db = torch.empty_like(x), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     ws = torch.empty(lib.load().spot_layernorm_bwd_ws_floats(rows, C), device="cuda")
-    t = timeit(lambda: lib.call("spot_layernorm_bwd_f32", P(y), P(x), P(mean), P(rstd), P(g), P(dx), P(dg), P(db), P(ws), rows, C, 0, ops._st()))
+    t = timeit(lambda: lib.call("spot_layernorm_bwd_f32", P(y), P(x), P(mean), P(rstd), P(g), P(dx), P(dg), P(db), P(ws), rows, C, 0, None, 0.0, 0, ops._st()))
     print("ln bwd  %7.1f us %7.1f GB/s" % (t * 1e6, 3 * x.numel() * 4 / t / 1e9))
     t = timeit(lambda: ops.colsum(x, out=dg))
     print("colsum  %7.1f us %7.1f GB/s" % (t * 1e6, x.numel() * 4 / t / 1e9))
