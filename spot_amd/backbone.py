@@ -84,7 +84,7 @@ class ResNet50Layer3(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = ops.max_pool_3x3_s2(ops.batch_norm_act(ops.conv_general(x, self.conv1), self.bn1, relu=True), self.maxpool)
+        x = ops.max_pool_3x3_s2(ops.conv_bn_act(x, self.conv1, self.bn1, relu=True), self.maxpool)
         return self.layer3(self.layer2(self.layer1(x)))
 
 

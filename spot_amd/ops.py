@@ -1264,9 +1264,11 @@ def conv_bn_act(x, conv, bn, relu=False):
     """[relu](bn(conv x)) for any nn.Conv2d this library runs.  With `bn` in inference mode and no gradient wanted, a
     3x3 convolution on the any-size Winograd path takes the normalisation (and ReLU) in its output transform, and
     keeps its transformed weights inside `with frozen_weights():`; otherwise conv_general -> batch_norm_act."""
-    fold = (x.shape[0] > 0 and not bn.training and bn.track_running_stats and not torch.is_grad_enabled()
-            and _winograd_general_applies(x, conv))
+    infer = x.shape[0] > 0 and not bn.training and bn.track_running_stats and not torch.is_grad_enabled() and x.is_cuda
+    fold = infer and _winograd_general_applies(x, conv)
     if not fold:
+        if infer and _im2col_fold_applies(x, conv):
+            return _conv_im2col_bn_act(x, conv, bn, relu)
         return batch_norm_act(conv_general(x, conv), bn, relu=relu)
     x = _chk(x.contiguous())
     B, Ci, H, W = x.shape
@@ -1291,6 +1293,57 @@ def conv_bn_act(x, conv, bn, relu=False):
     opts.bn_eps, opts.relu = float(bn.eps), int(relu)
     lib.call("spot_conv3x3_winograd_general_f32", _p(x), _p(weight), _p(conv.bias), _p(y), _p(ws), C.byref(opts), B, Ci, Co,
              H, W, int(pad), int(dh), int(dw_), 0, _st())
+    return y
+
+
+def _im2col_fold_applies(x, conv):
+    """Inference through the patch-matrix path with the normalisation in the product's epilogue: bias-free convolutions
+    outside both Winograd paths (the 7x7 / stride 2 stem, the strided 3x3) whose output map is a whole number of
+    32-position groups."""
+    s, p, d = conv.stride, conv.padding, conv.dilation
+    if not (conv.groups == 1 and conv.bias is None and s[0] == s[1] and isinstance(p, tuple) and p[0] == p[1]
+            and conv.padding_mode == "zeros" and x.dtype == torch.float32):
+        return False
+    if winograd_applies(x, conv) or _winograd_general_applies(x, conv):
+        return False
+    kh, kw = conv.kernel_size
+    Ho = (x.shape[2] + 2 * p[0] - d[0] * (kh - 1) - 1) // s[0] + 1
+    Wo = (x.shape[3] + 2 * p[0] - d[1] * (kw - 1) - 1) // s[0] + 1
+    return Ho > 0 and Wo > 0 and (Ho * Wo) % 32 == 0
+
+
+def _conv_im2col_bn_act(x, conv, bn, relu):
+    """[relu](bn(conv x)) in inference as patch matrix + one product whose epilogue normalises (per output channel =
+    per row of the product) and clamps; inside `frozen_weights` the zero-padded weight matrix is kept between calls."""
+    x = _chk(x.contiguous())
+    B, Ci, H, W = x.shape
+    weight = conv.weight
+    Co, _, kh, kw = weight.shape
+    stride, pad = conv.stride[0], conv.padding[0]
+    dh, dw_ = conv.dilation
+    K = Ci * kh * kw
+    Kpad = (K + 31) // 32 * 32
+    Ho = (H + 2 * pad - dh * (kh - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dw_ * (kw - 1) - 1) // stride + 1
+    N = Ho * Wo
+    dev = x.device
+    cols = torch.empty((B, Kpad, N), dtype=torch.float32, device=dev)
+    lib.call("spot_im2col_f32", _p(x), _p(cols), B, Ci, H, W, kh, kw, stride, pad, dh, dw_, Kpad, N, _st())
+    if Kpad == K:
+        wp = weight.view(Co, K)
+    else:
+        key = ("im2col weights", weight.data_ptr(), tuple(weight.shape))
+        hit = frozen_weights._tables.get(key) if frozen_weights._active else None
+        if hit is None:
+            wp = torch.zeros((Co, Kpad), dtype=torch.float32, device=dev)
+            wp[:, :K] = weight.view(Co, K)
+            if frozen_weights._active:
+                frozen_weights._tables[key] = (wp, weight)
+        else:
+            wp = hit[0]
+    y = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=dev)
+    gemm(wp, cols, y, Co, N, Kpad, transB=True, lda=Kpad, ldb=N, ldc=N, batch=B, strideB=Kpad * N, strideC=Co * N,
+         bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps), relu=1 if relu else 0)
     return y
 
 
@@ -1451,7 +1504,9 @@ def conv3x3_bn_act(x, conv, bn, relu=False):
     the normalisation and the ReLU ride in the Winograd output transform; otherwise conv3x3 -> batch_norm_act."""
     if (not bn.training and bn.track_running_stats and not torch.is_grad_enabled() and winograd_applies(x, conv)):
         return _winograd(_chk(x.contiguous()), conv.weight, conv.weight.shape[0], False, conv.dilation[0], bn=bn, relu=relu)
-    return batch_norm_act(conv3x3(x, conv), bn, relu=relu)
+    if winograd_applies(x, conv):
+        return batch_norm_act(conv3x3(x, conv), bn, relu=relu)
+    return conv_bn_act(x, conv, bn, relu=relu)
 
 
 # ---------------------------------------------------------------------------
