@@ -312,10 +312,14 @@ def _crop_desc(frame, x0, y0, crop, pad):
     return d
 
 
-def crop_resize_u8(frame, x0, y0, crop, out_sz, pad):
+def crop_resize_u8(frame, x0, y0, crop, out_sz, pad, out=None):
     """Window [y0, y0+crop) x [x0, x0+crop) of a uint8 HWC device frame, `pad` outside the frame, resized to
-    out_sz: uint8 [1, 3, out_sz, out_sz] (get_subwindow / sample_target of the reference, on the device)."""
-    out = torch.empty((1, 3, out_sz, out_sz), dtype=torch.uint8, device=frame.device)
+    out_sz: uint8 [1, 3, out_sz, out_sz] (get_subwindow / sample_target of the reference, on the device); written into
+    `out` when one of that shape is given."""
+    if out is None:
+        out = torch.empty((1, 3, out_sz, out_sz), dtype=torch.uint8, device=frame.device)
+    elif tuple(out.shape) != (1, 3, out_sz, out_sz) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device != frame.device:
+        raise RuntimeError("spot_amd: crop_resize_u8(out=...) must be a contiguous uint8 [1, 3, %d, %d] tensor on the frame's device" % (out_sz, out_sz))
     d = _crop_desc(frame, x0, y0, crop, pad)
     lib.call("spot_crop_resize_u8", C.byref(d), _p(out), int(out_sz), _st())
     return out

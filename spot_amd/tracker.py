@@ -103,6 +103,9 @@ class TransT_Tracker(object):
         (transt_tracker.py:41-101); returned as a uint8 [1,3,model_sz,model_sz] device tensor.  The window is cut,
         padded and resized by one kernel from the frame in device memory (`im` may already be a uint8 HWC CUDA
         tensor; a numpy frame is uploaded once per call of initialize / track)."""
+        return self._subwindow(im, pos, model_sz, original_sz, avg_chans, None)
+
+    def _subwindow(self, im, pos, model_sz, original_sz, avg_chans, out):
         if isinstance(pos, float):
             pos = [pos, pos]
         sz = int(original_sz)
@@ -110,7 +113,7 @@ class TransT_Tracker(object):
         context_xmin = np.floor(pos[0] - c + 0.5)
         context_ymin = np.floor(pos[1] - c + 0.5)
         pad = np.asarray(avg_chans, dtype=np.float64).astype(np.uint8)        # numpy's cast on assignment
-        return ops.crop_resize_u8(self._device_frame(im), int(context_xmin), int(context_ymin), sz, int(model_sz), pad)
+        return ops.crop_resize_u8(self._device_frame(im), int(context_xmin), int(context_ymin), sz, int(model_sz), pad, out=out)
 
     def _device_frame(self, im):
         """The frame as a uint8 HWC device tensor.  A host frame is uploaded once per initialize() / track() call
@@ -199,13 +202,19 @@ class TransT_Tracker(object):
                 return self._device_pipeline(x_crop)
             finally:
                 fusion.TWO_STREAMS = two
-        self._x_static.copy_(x_crop)
+        if x_crop is not self._x_static:                       # track() cuts the window straight into the graph's input
+            self._x_static.copy_(x_crop)
         self._graph.replay()
         return self._buf_static
 
     def track(self, image, info: dict = None) -> dict:
         s_x = self._crop_side(self.size, 4)
-        x_crop = self.get_subwindow(image, self.center_pos, self.instance_size, round(s_x), self.channel_average)
+        if self._graph is not None and "get_subwindow" not in self.__dict__ and type(self).get_subwindow is TransT_Tracker.get_subwindow:
+            # the frame replays as a graph: the window is cut straight into the graph's input buffer (a caller that has
+            # replaced get_subwindow keeps its own crop, which is then copied in)
+            x_crop = self._subwindow(image, self.center_pos, self.instance_size, round(s_x), self.channel_average, self._x_static)
+        else:
+            x_crop = self.get_subwindow(image, self.center_pos, self.instance_size, round(s_x), self.channel_average)
         self._frame = None
         res = self._run_frame(x_crop).cpu().numpy()            # the frame's one device->host read
         pscore = res[6:]
