@@ -235,6 +235,25 @@ int spot_gemm_pair_f32(const spot_gemm_desc* desc0 /* host */, const spot_gemm_d
  *             w = the forward weight as stored, Cin = its output channels, Cout = its input channels)
  * ws: spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W) floats of scratch.  opts: see the struct.  Results differ from a direct
  * convolution by fp32 rounding of the transforms (~1e-6 relative to the largest term). */
+/* Training-mode BatchNorm + ReLU of the convolution's INPUT, applied inside the input transform (bn1 -> relu -> conv2
+ * of a bottleneck, ltr/models/backbone/resnet.py:77-81, when the normalised map has no other reader): in = the raw
+ * output of the convolution in front, stats_ws = what spot_batchnorm_stats_f32(in, stats_ws, B, Cin, H*W) left.  The
+ * call stores save_mean / save_rstd [Cin], moves the running statistics (or leaves the update in deferred_stats, see
+ * spot_batchnorm_apply_deferred) and writes relu_sign (one byte per pack of four elements, as
+ * spot_batchnorm_fwd_train_f32 does) for spot_batchnorm_bwd_f32: same values as the stand-alone forward, bit for bit. */
+typedef struct spot_bn_train_in {
+    const float* stats_ws;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;            /* with running_var, or both NULL */
+    float* running_var;
+    long long* num_batches_tracked; /* or NULL */
+    float* save_mean;
+    float* save_rstd;
+    unsigned char* relu_sign;       /* B*Cin*H*W/4 bytes, or NULL when no backward follows */
+    float* deferred_stats;          /* [2*Cin] or NULL */
+    float eps, momentum;
+} spot_bn_train_in;
 typedef struct spot_winograd_opts {
     float* v_keep;          /* 36*Cin*B*(H/4)*(W/4) floats or NULL: receives the transformed input, for
                              * spot_conv3x3_winograd_wgrad_f32 to reuse                                                */
@@ -246,6 +265,7 @@ typedef struct spot_winograd_opts {
     const float* bn_var;    /* ltr/models/backbone/resnet.py:79-81, as the tracker and an eval() teacher run them)     */
     float bn_eps;
     int relu;
+    const spot_bn_train_in* in_bn;  /* host pointer or NULL; dilation 1, flip 0 only */
 } spot_winograd_opts;
 long spot_conv3x3_winograd_ws_floats(int B, int Cin, int Cout, int H, int W);
 int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws, const spot_winograd_opts* opts /* host, may be NULL */,
@@ -518,6 +538,9 @@ int spot_ocean_tracker_decode(const float* cls_logits, const float* align_logits
  * unbiased batch variance for a later spot_batchnorm_apply_deferred (pass the running buffers as NULL then).
  * ws: spot_batchnorm_ws_floats(N, C) floats. */
 long spot_batchnorm_ws_floats(int N, int C);
+/* The statistics pass of the training forward alone: per-slice partial sums into ws (spot_batchnorm_ws_floats(N, C)
+ * floats), for a consumer that applies the normalisation itself (spot_winograd_opts.in_bn). */
+int spot_batchnorm_stats_f32(const float* x, float* ws, int N, int C, int HW, hipStream_t stream);
 int spot_batchnorm_fwd_train_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, long long* num_batches_tracked, float* y,
                                  float* save_mean, float* save_rstd, unsigned char* relu_sign, float* deferred_stats,

@@ -39,6 +39,15 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         cb = ops.conv1x1_bn_act
+        if self._bn1_rides_in_conv2(x):
+            # training-mode bn1 + relu are taken by conv2's input transform: conv1's raw output goes straight in
+            if self.downsample is None:
+                raw, residual = ops.conv1x1(x, self.conv1, passthrough=True)
+            else:
+                raw = ops.conv1x1(x, self.conv1)
+                residual = cb(x, self.downsample[0], self.downsample[1])
+            out = ops.batch_norm_act(ops.bn_relu_conv3x3(raw, self.bn1, self.conv2), self.bn2, relu=True)
+            return cb(out, self.conv3, self.bn3, relu=True, residual=residual)
         if self.downsample is None:
             # identity branch handed through conv1: its gradient joins conv1's input gradient in one launch
             out, residual = cb(x, self.conv1, self.bn1, relu=True, passthrough=True)
@@ -47,6 +56,11 @@ class Bottleneck(nn.Module):
             residual = cb(x, self.downsample[0], self.downsample[1]) if self.downsample is not None else x
         out = ops.conv3x3_bn_act(out, self.conv2, self.bn2, relu=True)
         return cb(out, self.conv3, self.bn3, relu=True, residual=residual)
+
+    def _bn1_rides_in_conv2(self, x):
+        # conv1 is 1x1 / stride 1: its output has x's spatial size
+        return (self.conv1.stride == (1, 1) and x.dtype == torch.float32
+                and ops.bn_relu_conv3x3_applies(self.bn1, self.conv2, x.shape[0], x.shape[2], x.shape[3], x.is_cuda))
 
 
 class ResNet50Layer3(nn.Module):

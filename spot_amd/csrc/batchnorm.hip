@@ -14,19 +14,14 @@
 // combined by every consumer workgroup from the per-slice partials (at most 64 pairs),
 // so there is no finalize launch and no atomics: results are bit-reproducible.
 #include "common.h"
+#include "bn_train.h"
 #include "../../include/spot_hip.h"
 
 namespace {
 
-constexpr int MAX_SPLIT = 64;
-
-__device__ __forceinline__ float block_sum(float v, float* red) {   // red: 4 floats of LDS; all threads get the sum
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
+using spot_bn::block_sum;
+using spot_bn::combine;
+using spot_bn::split_for;
 
 struct Slice {
     int n0, n1;
@@ -102,17 +97,6 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-// combine the S partial pairs of channel c (every thread returns the totals)
-__device__ __forceinline__ void combine(const float* __restrict__ partial, int c, int S, float& a, float& b, float* red) {
-    float pa = 0.f, pb = 0.f;
-    if ((int)threadIdx.x < S) {
-        pa = partial[((size_t)c * S + threadIdx.x) * 2];
-        pb = partial[((size_t)c * S + threadIdx.x) * 2 + 1];
-    }
-    a = block_sum(pa, red);
-    b = block_sum(pb, red);
-}
-
 // ---- pass 2 (training): normalise, affine, (+ residual), (relu), sign byte (bit j: element j of the pack was > 0)
 template <bool RELU, bool RES, int VW>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
@@ -125,28 +109,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        int N, int C, int HWV, int S, float eps, float momentum) {
     __shared__ float red[4];
     const int c = blockIdx.x, s = blockIdx.y;
-    float s1, s2;
-    combine(partial, c, S, s1, s2, red);
     const float M = (float)N * (float)(HWV * VW);
     const float K = x[(size_t)c * HWV * VW];
-    const float dm = s1 / M;
-    const float mean = K + dm;
-    const float var = fmaxf(s2 / M - dm * dm, 0.f);
-    const float rstd = rsqrtf(var + eps);
-    if (s == 0 && threadIdx.x == 0) {
-        save_mean[c] = mean;
-        save_rstd[c] = rstd;
-        if (run_mean) {
-            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
-            run_var[c] = (1.f - momentum) * run_var[c] + momentum * (var * (M / (M - 1.f)));
-        }
-        if (tracked && c == 0) *tracked += 1;
-        if (deferred) {
-            deferred[c] = mean;
-            deferred[C + c] = var * (M / (M - 1.f));
-        }
-    }
-    const float a = rstd * gamma[c], b = beta[c] - mean * a;
+    const spot_bn::TrainStats ts = {partial, S, gamma, beta, run_mean, run_var, tracked, save_mean, save_rstd, deferred, eps, momentum};
+    float a, b;
+    spot_bn::channel_affine(ts, c, C, K, M, s == 0 && threadIdx.x == 0, red, a, b);
     const Slice sl = slice_of(N, S, s);
     for (int n = sl.n0 + (int)threadIdx.x / HWV, i = (int)threadIdx.x % HWV; n < sl.n1; advance(n, i, HWV)) {
         const size_t off = ((size_t)n * C + c) * HWV + i;
@@ -279,14 +246,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
-int split_for(int N, int C) {
-    int S = 2048 / C;
-    if (S < 1) S = 1;
-    if (S > N) S = N;
-    if (S > MAX_SPLIT) S = MAX_SPLIT;
-    return S;
-}
-
 bool shape_ok(int N, int C, int HW) { return N > 0 && C > 0 && HW > 0 && C <= 65535; }
 // 16-byte packs need whole float4s per plane and aligned buffers; anything else is walked element by element
 bool vec4(int HW, uintptr_t ptrs) { return HW % 4 == 0 && (ptrs & 15) == 0; }
@@ -294,6 +253,17 @@ bool vec4(int HW, uintptr_t ptrs) { return HW % 4 == 0 && (ptrs & 15) == 0; }
 }  // namespace
 
 extern "C" long spot_batchnorm_ws_floats(int N, int C) { return (long)C * split_for(N > 0 ? N : 1, C > 0 ? C : 1) * 2; }
+
+extern "C" int spot_batchnorm_stats_f32(const float* x, float* ws, int N, int C, int HW, hipStream_t stream) {
+    SPOT_CHECK_ARG(shape_ok(N, C, HW), "batchnorm_stats: bad shape N=%d C=%d HW=%d", N, C, HW);
+    SPOT_CHECK_ARG(x && ws && ((uintptr_t)x & 3) == 0, "batchnorm_stats: null or misaligned pointer");
+    const int S = split_for(N, C);
+    dim3 grid(C, S);
+    if (vec4(HW, (uintptr_t)x)) bn_stats_kernel<4><<<grid, 256, 0, stream>>>(x, ws, N, C, HW / 4, S);
+    else bn_stats_kernel<1><<<grid, 256, 0, stream>>>(x, ws, N, C, HW, S);
+    SPOT_CHECK_LAUNCH("batchnorm_stats");
+    return SPOT_OK;
+}
 
 extern "C" int spot_batchnorm_fwd_train_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                                             float* running_mean, float* running_var, long long* num_batches_tracked,

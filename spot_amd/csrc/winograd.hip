@@ -14,6 +14,7 @@
 // In steps 2 and 4 a thread owns one tile of one channel; lanes run along p, so every access to V / M is a
 // coalesced 256-byte row segment per wave.
 #include "common.h"
+#include "bn_train.h"
 #include "../../include/spot_hip.h"
 
 namespace {
@@ -99,10 +100,26 @@ struct TileGeo {
 };
 
 // V[xi][c][p] = (B^T d B)[xi], d = the 6x6 input patch of tile p (rows 4ty-1 .. 4ty+4, zero outside the map)
-template <int D>
+// INBN (D = 1): the input is the raw output of the 1x1 convolution in front; its training-mode BatchNorm and ReLU
+// (bn1 -> relu of a bottleneck, resnet.py:77-79) are applied to every element on its way into the patch - the
+// normalised map itself is needed by nobody else and is never written.  The workgroup (one channel) derives the
+// channel's affine map from the statistics pass's partial sums exactly as the stand-alone apply kernel does; the
+// thread that owns a 4x4 tile writes the sign bytes of its four 4-element packs for the BatchNorm backward.
+struct InBn {
+    spot_bn::TrainStats t;
+    unsigned char* sign;
+    int N;
+};
+template <int D, bool INBN>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int C, int H,
-                                                         int W, int P) {
+                                                         int W, int P, InBn bn) {
     const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    float a = 1.f, b = 0.f;
+    if (INBN) {
+        __shared__ float red[4];
+        const float M = (float)bn.N * (float)(H * W);
+        spot_bn::channel_affine(bn.t, c, C, x[(size_t)c * H * W], M, blockIdx.x == 0 && threadIdx.x == 0, red, a, b);
+    }
     if (p >= P) return;
     const TileGeo<D> g(x, p, c, C, H, W);
     float tmp[6][6];      // B^T d, built column by column after loading the patch rows
@@ -121,6 +138,18 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
             }
             d[i][0] = g.c0 > 0 ? rp[-D] : 0.f;
             d[i][5] = g.c0 + 4 < g.Ws ? rp[4 * D] : 0.f;
+            if (INBN) {
+                unsigned m = 0;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const float t = fmaf(d[i][j], a, b);
+                    if (j >= 1 && j <= 4) m |= (unsigned)(t > 0.f) << (j - 1);
+                    d[i][j] = fmaxf(t, 0.f);
+                }
+                if (g.c0 == 0) d[i][0] = 0.f;                    // outside the map stays zero
+                if (g.c0 + 4 >= g.Ws) d[i][5] = 0.f;
+                if (bn.sign && i >= 1 && i <= 4) bn.sign[(size_t)(rp - x) >> 2] = (unsigned char)m;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 6; ++j) d[i][j] = 0.f;
@@ -484,6 +513,12 @@ extern "C" long spot_conv3x3_winograd_ws_floats(int B, int Cin, int Cout, int H,
         else kernel<2><<<grid, 256, 0, stream>>>(__VA_ARGS__);                \
     } while (0)
 
+#define WINO_LAUNCH_IN(dil, grid, ...)                                                        \
+    do {                                                                                      \
+        if ((dil) == 1) wino_input_kernel<1, false><<<grid, 256, 0, stream>>>(__VA_ARGS__, InBn{}); \
+        else wino_input_kernel<2, false><<<grid, 256, 0, stream>>>(__VA_ARGS__, InBn{});           \
+    } while (0)
+
 extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float* out, float* ws,
                                          const spot_winograd_opts* opts, int B, int Cin, int Cout, int H, int W,
                                          int dilation, int flip, hipStream_t stream) {
@@ -512,7 +547,18 @@ extern "C" int spot_conv3x3_winograd_f32(const float* in, const float* w, float*
         wino_weights_kernel<<<spot_ceil_div((long)Cout * Cin, 256), 256, 0, stream>>>(w, U, Cout, Cin, flip);
         SPOT_CHECK_LAUNCH("conv3x3_winograd(weights)");
     }
-    WINO_LAUNCH(wino_input_kernel, dilation, dim3(spot_ceil_div(P, 256), Cin), in, V, Cin, H, W, P);
+    if (opts && opts->in_bn) {
+        const spot_bn_train_in* ib = opts->in_bn;
+        SPOT_CHECK_ARG(dilation == 1 && !flip, "conv3x3_winograd: in_bn needs dilation 1 and the forward direction");
+        SPOT_CHECK_ARG(ib->stats_ws && ib->gamma && ib->beta && ib->save_mean && ib->save_rstd, "conv3x3_winograd: in_bn null pointer");
+        SPOT_CHECK_ARG((ib->running_mean == nullptr) == (ib->running_var == nullptr), "conv3x3_winograd: in_bn running stats come in pairs");
+        InBn bn_in = {{ib->stats_ws, spot_bn::split_for(B, Cin), ib->gamma, ib->beta, ib->running_mean, ib->running_var,
+                       ib->num_batches_tracked, ib->save_mean, ib->save_rstd, ib->deferred_stats, ib->eps, ib->momentum},
+                      ib->relu_sign, B};
+        wino_input_kernel<1, true><<<dim3(spot_ceil_div(P, 256), Cin), 256, 0, stream>>>(in, V, Cin, H, W, P, bn_in);
+    } else {
+        WINO_LAUNCH_IN(dilation, dim3(spot_ceil_div(P, 256), Cin), in, V, Cin, H, W, P);
+    }
     SPOT_CHECK_LAUNCH("conv3x3_winograd(input)");
     spot_gemm_desc d = {};
     d.A = U; d.B = V; d.C = Mb;
@@ -551,7 +597,7 @@ extern "C" int spot_conv3x3_winograd_wgrad_f32(const float* x, const float* v_ke
     float* dM = Vown + s.V;
     const float* V = v_kept;
     if (!V) {
-        WINO_LAUNCH(wino_input_kernel, dilation, dim3(spot_ceil_div(P, 256), Cin), x, Vown, Cin, H, W, P);
+        WINO_LAUNCH_IN(dilation, dim3(spot_ceil_div(P, 256), Cin), x, Vown, Cin, H, W, P);
         SPOT_CHECK_LAUNCH("conv3x3_winograd_wgrad(input)");
         V = Vown;
     }
@@ -599,6 +645,7 @@ extern "C" int spot_conv3x3_winograd_general_f32(const float* in, const float* w
                                                  int Win, int pad, int dil_h, int dil_w, int flip, hipStream_t stream) {
     float* v_keep = opts ? opts->v_keep : nullptr;
     float* u_keep = opts ? opts->u_keep : nullptr;
+    SPOT_CHECK_ARG(!(opts && opts->in_bn), "conv3x3_winograd_general: in_bn is taken by spot_conv3x3_winograd_f32 only");
     OutAffine bn = {nullptr, nullptr, nullptr, nullptr, 0.f, 0};
     if (opts && opts->bn_gamma) {
         SPOT_CHECK_ARG(opts->bn_beta && opts->bn_mean && opts->bn_var, "conv3x3_winograd_general: bn_gamma needs bn_beta, bn_mean, bn_var");

@@ -43,10 +43,17 @@ class CropDesc(C.Structure):
                 ("crop", C.c_int), ("pad", C.c_ubyte * 4)]
 
 
+class BnTrainIn(C.Structure):
+    """Mirror of ``spot_bn_train_in``."""
+    _fields_ = [("stats_ws", vp), ("gamma", vp), ("beta", vp), ("running_mean", vp), ("running_var", vp),
+                ("num_batches_tracked", vp), ("save_mean", vp), ("save_rstd", vp), ("relu_sign", vp),
+                ("deferred_stats", vp), ("eps", f32), ("momentum", f32)]
+
+
 class WinogradOpts(C.Structure):
     """Mirror of ``spot_winograd_opts``."""
     _fields_ = [("v_keep", vp), ("u_keep", vp), ("u_valid", i32), ("bn_gamma", vp), ("bn_beta", vp), ("bn_mean", vp),
-                ("bn_var", vp), ("bn_eps", f32), ("relu", i32)]
+                ("bn_var", vp), ("bn_eps", f32), ("relu", i32), ("in_bn", C.POINTER(BnTrainIn))]
 
 
 # name -> argument ctypes (all return int unless noted); the trailing hipStream_t is a void*
@@ -113,6 +120,7 @@ SIGNATURES = {
     "spot_mha_dropout_mask": [vp, i32, i32, i32, i32, f32, C.c_uint, vp],
     "spot_dropout_f32": [vp, vp, i64, i32, f32, C.c_uint, vp],
     "spot_layernorm_fwd_f32": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
+    "spot_batchnorm_stats_f32": [vp, vp, i32, i32, i32, vp],
     "spot_layernorm_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, f32, C.c_uint, vp],
 }
 

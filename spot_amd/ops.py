@@ -1486,6 +1486,117 @@ class Conv3x3Fn(_Fn):
         return dx, dw, None
 
 
+class BnReluConv3x3Fn(_Fn):
+    """conv2(relu(bn1(x))) of a bottleneck in training mode (resnet.py:77-81), x = the raw output of conv1.
+
+    The normalised map has one reader, the 3x3 convolution's Winograd input transform, so it is never written: a
+    statistics pass over x, then the input transform normalises and clamps each element on its way in (and writes the
+    ReLU sign bytes).  One pass over the map and one launch less than batch_norm_act -> conv3x3, same values bit for
+    bit.  Backward: the convolution's two gradients as Conv3x3Fn, then the BatchNorm backward as BatchNormActFn."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, tracked, eps, momentum, weight, deferred=None):
+        x = _chk(x.contiguous())
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dev = x.device
+        L = lib.load()
+        need = _wants(ctx)
+        keep_v = _wants(ctx, 8)                           # the transformed input serves the weight gradient too
+        stats_ws = torch.empty((L.spot_batchnorm_ws_floats(B, Cin),), dtype=torch.float32, device=dev)
+        lib.call("spot_batchnorm_stats_f32", _p(x), _p(stats_ws), B, Cin, H * W, _st())
+        mean = torch.empty((Cin,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((Cin,), dtype=torch.float32, device=dev)
+        sign = torch.empty((x.numel() // 4,), dtype=torch.uint8, device=dev) if need else None
+        ib = lib.BnTrainIn()
+        ib.stats_ws, ib.gamma, ib.beta = stats_ws.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+        ib.running_mean = running_mean.data_ptr() if running_mean is not None else None
+        ib.running_var = running_var.data_ptr() if running_var is not None else None
+        ib.num_batches_tracked = tracked.data_ptr() if tracked is not None else None
+        ib.save_mean, ib.save_rstd = mean.data_ptr(), rstd.data_ptr()
+        ib.relu_sign = sign.data_ptr() if sign is not None else None
+        ib.deferred_stats = deferred.data_ptr() if deferred is not None else None
+        ib.eps, ib.momentum = float(eps), float(momentum)
+        lib.keep(stats_ws, gamma, beta, running_mean, running_var, tracked, mean, rstd, sign, deferred)
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=dev)
+        ws = torch.empty((L.spot_conv3x3_winograd_ws_floats(B, Cin, Cout, H, W),), dtype=torch.float32, device=dev)
+        v = torch.empty((36, Cin, B * (H // 4) * (W // 4)), dtype=torch.float32, device=dev) if keep_v else None
+        opts = lib.WinogradOpts()
+        opts.v_keep = v.data_ptr() if v is not None else None
+        opts.in_bn = C.pointer(ib)
+        lib.call("spot_conv3x3_winograd_f32", _p(x), _p(weight), _p(out), _p(ws), C.byref(opts), B, Cin, Cout, H, W, 1, 0,
+                 _st())
+        if need:
+            ctx.save_for_backward(x, sign, mean, rstd, gamma, weight, v)
+            ctx.params = (gamma, beta, weight)
+            if _sink(gamma) is not None and _sink(beta) is not None:
+                _sink_expect(gamma, beta)
+            if keep_v:
+                _sink_expect(weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, sign, mean, rstd, gamma, weight, v = ctx.saved_tensors
+        pg, pb, pw = ctx.params
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dev = dout.device
+        dout = dout.contiguous()
+        L = lib.load()
+        dw = None
+        if ctx.needs_input_grad[8]:
+            sk = _sink(pw)
+            dw = sk if sk is not None else torch.empty_like(weight)
+            ws = torch.empty((L.spot_conv3x3_winograd_wgrad_ws_floats(B, Cin, Cout, H, W),), dtype=torch.float32, device=dev)
+            lib.call("spot_conv3x3_winograd_wgrad_f32", None, _p(v), _p(dout), _p(dw), _p(ws), B, Cin, Cout, H, W, 1,
+                     int(sk is not None), _st())
+            if sk is not None:
+                dw = None
+                _sink_done(pw)
+        dx = dg = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dy = _winograd(dout, weight, Cin, True, 1)       # gradient behind the ReLU
+            dx = torch.empty_like(x)
+            sg, sb = _sink(pg), _sink(pb)
+            direct = sg is not None and sb is not None
+            dg = sg if direct else torch.empty_like(gamma)
+            db = sb if direct else torch.empty_like(gamma)
+            ws = torch.empty((L.spot_batchnorm_ws_floats(B, Cin),), dtype=torch.float32, device=dev)
+            lib.call("spot_batchnorm_bwd_f32", _p(dy), _p(x), _p(sign), _p(mean), _p(rstd), _p(gamma), _p(dx), None,
+                     _p(dg), _p(db), _p(ws), B, Cin, H * W, int(direct), _st())
+            if direct:
+                _sink_done(pg, pb)
+                dg = db = None
+        return dx, dg, db, None, None, None, None, None, dw, None
+
+
+FUSE_BN_INTO_CONV3X3 = True     # scheduling switch: False runs batch_norm_act -> conv3x3 (same values)
+
+
+def bn_relu_conv3x3_applies(bn, conv, B, H, W, is_cuda):
+    """Training-mode BatchNorm + ReLU in front of a bias-free 3x3 / stride 1 / padding 1 convolution on a B x . x H x W
+    map of the Winograd path, dilation 1 (the dilated one works on polyphase sub-maps whose packs of four are not the
+    map's)."""
+    return (FUSE_BN_INTO_CONV3X3 and is_cuda and B > 0 and (bn.training or not bn.track_running_stats)
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.padding == (1, 1)
+            and conv.groups == 1 and conv.bias is None and H % 4 == 0 and W % 4 == 0)
+
+
+def bn_relu_conv3x3(x, bn, conv):
+    """conv(relu(bn(x))) with bn in training mode: see BnReluConv3x3Fn (statistics handling as batch_norm_act)."""
+    if bn.momentum is None:
+        raise RuntimeError("spot_amd: cumulative-average BatchNorm (momentum=None) is not supported")
+    track = bn.track_running_stats
+    pending = defer_running_stats._active
+    if track and pending is not None:
+        return BnReluConv3x3Fn.apply(x, bn.weight, bn.bias, None, None, None, bn.eps, bn.momentum, conv.weight,
+                                     pending.buffer_for(bn))
+    return BnReluConv3x3Fn.apply(x, bn.weight, bn.bias, bn.running_mean if track else None,
+                                 bn.running_var if track else None, bn.num_batches_tracked if track else None, bn.eps,
+                                 bn.momentum, conv.weight)
+
+
 def conv3x3(x, conv):
     """nn.Conv2d `conv` applied to x: the Winograd path for bias-free 3x3 / stride 1 convolutions with dilation d = 1
     or 2 and padding d on maps whose sides are multiples of 4d; everything else goes to conv_general (any-size

@@ -630,6 +630,69 @@ def test_layernorm_backward_hands_the_masked_gradient_to_the_block_before_it(ops
         assert torch.equal(u, w)
 
 
+@pytest.mark.parametrize("downsample", [False, True])
+def test_bottleneck_bn1_inside_the_input_transform_equals_the_separate_pass(ops, downsample):
+    """Training-mode bn1 + relu taken by conv2's Winograd input transform (no normalised map is written): output, input
+    gradient, every parameter gradient, running statistics and the deferred-statistics variant equal the
+    batch_norm_act -> conv3x3 sequence bit for bit."""
+    from spot_amd.backbone import Bottleneck
+    import torch.nn as nn
+    inpl, planes, B, H, W = (64, 32, 3, 24, 32) if downsample else (128, 32, 3, 24, 32)
+    ds = nn.Sequential(nn.Conv2d(inpl, planes * 4, 1, bias=False), nn.BatchNorm2d(planes * 4)) if downsample else None
+    blk = _load_det(Bottleneck(inpl, planes, 1, ds), 33).to(DEV).train()
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.5, 0.5)
+    x0 = G(det_input("x", (B, inpl, H, W), 33, -1, 1))
+    up = G(det_input("up", (B, planes * 4, H, W), 34, -1, 1))
+    start = {k: v.clone() for k, v in blk.state_dict().items()}
+
+    def run(fused, deferred):
+        blk.load_state_dict(start)
+        for q in blk.parameters():
+            q.grad = None
+        ops.FUSE_BN_INTO_CONV3X3 = fused
+        try:
+            x = x0.clone().requires_grad_()
+            if deferred:
+                with ops.defer_running_stats() as pending:
+                    y = blk(x)
+                pending.apply()
+            else:
+                y = blk(x)
+            (y * up).sum().backward()
+        finally:
+            ops.FUSE_BN_INTO_CONV3X3 = True
+        return [y.detach(), x.grad] + [q.grad.clone() for q in blk.parameters()] + [v.clone() for v in blk.state_dict().values()]
+
+    for deferred in (False, True):
+        a, b = run(True, deferred), run(False, deferred)
+        assert len(a) == len(b)
+        n_conv = 0
+        for i, (u, w) in enumerate(zip(a, b)):
+            if i >= 2 and u.dim() == 4 and u.is_floating_point() and u.shape[1] > 1 and i < 2 + len(list(blk.parameters())):
+                # convolution weight gradients: summed over the batch by split-K atomics, whose order is not fixed
+                assert float((u - w).abs().max()) <= 1e-5 * float(w.abs().max()), i
+                n_conv += 1
+            else:
+                assert torch.equal(u, w), i
+        assert n_conv >= 3
+    with torch.no_grad():                           # a pass that needs no gradient (the teacher in its train() mode)
+        blk.load_state_dict(start)
+        y1 = blk(x0)
+        s1 = {k: v.clone() for k, v in blk.state_dict().items()}
+        blk.load_state_dict(start)
+        ops.FUSE_BN_INTO_CONV3X3 = False
+        try:
+            y2 = blk(x0)
+        finally:
+            ops.FUSE_BN_INTO_CONV3X3 = True
+        assert torch.equal(y1, y2)
+        for k, v in blk.state_dict().items():
+            assert torch.equal(v, s1[k]), k
+
+
 def test_xcorr_backward_golden(ops, golden):
     g = golden("g12_xcorr")
     for tag in ("ocean255", "cfg5"):
