@@ -595,8 +595,8 @@ def test_fusion_layer_train_mode_dropout_is_reproducible_and_unbiased(ops):
 
 def test_layernorm_backward_hands_the_masked_gradient_to_the_block_before_it(ops, monkeypatch):
     """The gradient behind a block's output dropout comes out of the following LayerNorm's backward kernel as a second
-    output; the block's backward uses it instead of a pass of its own.  Same gradients bit for bit either way, and the
-    stand-alone dropout pass is not launched when the hand-over works."""
+    output; the block's backward uses it instead of a pass of its own.  Same gradients either way, and the stand-alone
+    dropout pass is not launched when the hand-over works."""
     from spot_amd.fusion import FeatureFusionLayer
     d, nh, ff, B, Lt, Ls = 64, 2, 128, 2, 32, 96
     layer = _load_det(FeatureFusionLayer(d, nh, ff, 0.1), 21).train()
@@ -627,7 +627,9 @@ def test_layernorm_backward_hands_the_masked_gradient_to_the_block_before_it(ops
     ops._DROPPED.clear()                         # (the copies nobody asked for; a training step clears them too)
     assert n_without >= 6 and n_with == 0, (n_with, n_without)
     for u, w in zip(with_it, without):
-        assert torch.equal(u, w)
+        # the same masked values enter the same products; weight gradients are summed by split-K atomics, whose order
+        # differs from run to run in the last bit
+        assert float((u - w).abs().max()) <= 2e-6 * float(w.abs().max())
 
 
 @pytest.mark.parametrize("downsample", [False, True])
