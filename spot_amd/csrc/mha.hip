@@ -129,6 +129,9 @@ __device__ __forceinline__ void push_bit(unsigned& packed, unsigned long long ma
     unsigned long long carry_out;
     asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(packed), "=s"(carry_out) : "s"(mask));
 }
+// DROPC: what the caller knows at compile time about dropout: -1 nothing (decided per call from drop_thr / keep_out),
+// 0 off, 1 on, 2 on with keep bits (keep_out may still be null for a lane whose query lies past the end)
+template <int DROPC = -1>
 __device__ __forceinline__ void softmax_block(bool check, f32x16& s, f32x16& o, float& m_ref, float& l_run, int key0, int h, int Lk,
                                               const unsigned char* mb, unsigned qs, unsigned drop_thr, float drop_scale,
                                               unsigned short* keep_out = nullptr) {
@@ -162,7 +165,7 @@ __device__ __forceinline__ void softmax_block(bool check, f32x16& s, f32x16& o, 
         const f32x2v a2 = a4.lo + a4.hi;
         l_run += a2.x + a2.y;
     }
-    if (drop_thr) {   // dropout acts on the normalised probabilities: the row sum above stays undropped
+    if (DROPC < 0 ? drop_thr != 0 : DROPC > 0) {   // dropout acts on the normalised probabilities: the row sum above stays undropped
         // keys of accumulator elements (e, e + 1), e even: key0 + 4h + r, r = acc_row(e, 0) even, and r + 1
         const unsigned x0 = qs ^ (unsigned)(key0 + 4 * h);   // low 16 bits: key
         s = s * drop_scale;
@@ -176,7 +179,7 @@ __device__ __forceinline__ void softmax_block(bool check, f32x16& s, f32x16& o, 
             s[e] = k0 ? s[e] : 0.f;
             s[e + 1] = k1 ? s[e + 1] : 0.f;
         }
-        if (keep_out) {                            // a backward follows: the 16 bits, element 0 at bit 15
+        if ((DROPC < 0 || DROPC == 2) && keep_out) {   // a backward follows: the 16 bits, element 0 at bit 15
             unsigned packed = 0;
 #pragma unroll
             for (int e = 0; e < 16; ++e) push_bit(packed, keep[e]);
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(256, 3) void mha_fwd_pair_kernel(MhaFwdArgs A0, Mha
 // j is fetched to registers in global phase 2j-2, written to LDS in 2j-1 and
 // first read in 2j; its slot's previous tenant j-3 was last read in phase 2j-3.
 // ---------------------------------------------------------------------------
+template <int DROPC>
 __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
     const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
     float* __restrict__ O, long ldo, float* __restrict__ LSE, const unsigned char* __restrict__ kpm,
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
     };
     auto softmax = [&](int j, f32x16& s) {
         const int key0 = j * 32;
-        softmax_block(mb || key0 + 32 > Lk, s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale, keep_lane);
+        softmax_block<DROPC>(mb || key0 + 32 > Lk, s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale, keep_lane);
     };
 
     fetch(0);
@@ -486,8 +490,13 @@ static int mha_fwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
     } else if (Lq >= 512 && (long)((Lq + 255) / 256) * nhead * B >= 512) {
         // 256-query workgroups need enough of them to fill the chip; short query streams keep the 128-query kernel
         dim3 grid((Lq + 255) / 256, nhead, B);
-        mha_fwd_pp_kernel<<<grid, 512, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk, nhead,
-                                                    scale, thr, drop_seed, dscale, drop_bits);
+#define SPOT_MHA_PP(D)                                                                                                    \
+    mha_fwd_pp_kernel<D><<<grid, 512, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk, nhead, \
+                                                   scale, thr, drop_seed, dscale, drop_bits)
+        if (!thr) SPOT_MHA_PP(0);
+        else if (drop_bits) SPOT_MHA_PP(2);
+        else SPOT_MHA_PP(1);
+#undef SPOT_MHA_PP
     } else {
         dim3 grid((Lq + 127) / 128, nhead, B);
         mha_fwd_kernel<false><<<grid, 256, 0, stream>>>(MhaFwdArgs{q, ldq, k, ldk, v, ldv, out, ldo, lse, key_padding_mask, Lq, Lk,
