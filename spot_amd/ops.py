@@ -1919,7 +1919,6 @@ class MHAFn(_Fn):
         sinks = [_sink(t) for t in ctx.params]
         d_out_b = _bias_grad_buffer(sinks[3], Cn, dev)
         d_out_w = linear_wgrad(dzd, attn, out=sinks[2], accumulate=sinks[2] is not None, bias_out=d_out_b)
-        delta = torch.empty((B, nhead, Lq), dtype=torch.float32, device=dev)
         scale = 1.0 / math.sqrt(dh)
         d_in_w = sinks[0] if sinks[0] is not None else torch.zeros_like(in_w)
         d_in_b = sinks[1] if sinks[1] is not None else torch.zeros((3 * Cn,), dtype=torch.float32, device=dev)
@@ -1927,7 +1926,7 @@ class MHAFn(_Fn):
             dqkv = torch.empty_like(qkv)
             _timed_mha_bwd(B, Lq, Lk, nhead, dh, lambda: lib.call(
                 ctx.bwd_entry, _p(qkv), 3 * Cn, _p(qkv[:, Cn:]), 3 * Cn, _p(qkv[:, 2 * Cn:]), 3 * Cn,
-                _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
+                _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), None,
                 _p(dqkv), 3 * Cn, _p(dqkv[:, Cn:]), 3 * Cn, _p(dqkv[:, 2 * Cn:]), 3 * Cn,
                 B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _p(keep), _st()))
             dxq = linear_dgrad(dqkv, in_w, residual=dz2 if has_res else None)
@@ -1941,7 +1940,7 @@ class MHAFn(_Fn):
             dkv = torch.empty_like(kv)
             _timed_mha_bwd(B, Lq, Lk, nhead, dh, lambda: lib.call(
                 ctx.bwd_entry, _p(qkv), Cn, _p(kv), 2 * Cn, _p(kv[:, Cn:]), 2 * Cn,
-                _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), _p(delta),
+                _p(attn), Cn, _p(dattn), Cn, _p(lse), _p(kpm), None,
                 _p(dq), Cn, _p(dkv), 2 * Cn, _p(dkv[:, Cn:]), 2 * Cn,
                 B, Lq, Lk, nhead, dh, scale, float(p_attn), sa, _p(keep), _st()))
             dxq = linear_dgrad(dq, in_w[:Cn], residual=dz2 if has_res else None)
