@@ -370,10 +370,10 @@ int spot_channel_sum_f32(const float* x, int B, int C, long HW, float* out, hipS
  * drop_p > 0: dropout on the attention probabilities (nn.MultiheadAttention(dropout=...), :121,172-175) with a
  * counter-based mask of (drop_seed, clip, head, query, key).
  * drop_bits (NULL, or spot_mha_drop_bits_words(B, nhead, Lq, Lk) 32-bit words): with drop_p > 0 the forward also
- * writes the mask it drew, one bit per (query, key), for the backward call, which then spends two instructions per
- * element on the mask instead of recomputing the hash (1024 x 1024, 40 clips: backward 1137 -> 1078 us, forward
- * 434 -> 445 us).  A backward
- * call given NULL regenerates the mask from the seed; both give the same gradients. */
+ * writes the mask it drew, one bit per (query, key), for the backward call, which then reads the words with scalar
+ * loads and spends one select per element on the mask instead of recomputing the hash (1024 x 1024, 40 clips:
+ * backward 1137 -> 1040 us, forward 434 -> 440 us).  The buffer is 8-byte aligned; its word order is private to the
+ * two calls.  A backward call given NULL regenerates the mask from the seed; both give the same gradients. */
 long spot_mha_drop_bits_words(int B, int nhead, int Lq, int Lk);
 int spot_mha_fwd_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                      float* out, long ldo, float* lse, const unsigned char* key_padding_mask, int B,

@@ -99,10 +99,12 @@ __device__ __forceinline__ bool attn_keep(unsigned sbh, unsigned q, unsigned key
     return ((key & 1u) ? bits >> 16 : bits & 0xffffu) >= thr16;
 }
 // Keep bits for the backward pass.  A forward pass that is followed by a backward writes the mask it drew as one bit
-// per (query, key): 32-bit word [clip*head][query tile of 32][key tile of 32][query in tile] holds the 32 keys of the
-// tile for one query, in the order the forward's lanes own them: the low half belongs to the lane half h = 0, the
-// high half to h = 1, and inside a half accumulator element e (key acc_row(e, h) of the tile) sits at bit 15 - e.
-// The backward then spends two instructions per element (bit-field extract, and) instead of the hash.
+// per (query, key): 32-bit word [clip*head][query tile of 32][key tile of 32][slot] holds the 32 keys of the tile for
+// one query, key k of the tile at bit k.  The query's slot is attn_bits_slot(query in tile): the order in which the
+// backward's accumulator rows meet the queries, so that words 2e and 2e + 1 together are the 64-lane mask (keys on the
+// lanes, lane half h on query acc_row(e, h)) of its element e.  The backward reads them with scalar loads and spends
+// ONE select per element, with the mask in scalar registers, instead of the hash.
+__device__ __forceinline__ int attn_bits_slot(int q31) { return 2 * ((q31 & 3) + 4 * (q31 >> 3)) + ((q31 >> 2) & 1); }
 __device__ __forceinline__ long attn_bits_words(int Lq, int Lk) { return (long)((Lq + 31) / 32) * ((Lk + 31) / 32) * 32; }
 // 16-bit threshold of the pair hash from the library-wide 32-bit one (0 = dropout off; a rate below 2^-16 rounds up)
 static inline unsigned attn_threshold(float p) {
@@ -130,11 +132,12 @@ __device__ __forceinline__ void push_bit(unsigned& packed, unsigned long long ma
     asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(packed), "=s"(carry_out) : "s"(mask));
 }
 // DROPC: what the caller knows at compile time about dropout: -1 nothing (decided per call from drop_thr / keep_out),
-// 0 off, 1 on, 2 on with keep bits (keep_out may still be null for a lane whose query lies past the end)
+// 0 off, 1 on, 2 on with keep bits (keep_out: the word of the lane's query in the first key tile; null, for the whole
+// wave, when its 32 queries all lie past the end)
 template <int DROPC = -1>
 __device__ __forceinline__ void softmax_block(bool check, f32x16& s, f32x16& o, float& m_ref, float& l_run, int key0, int h, int Lk,
-                                              const unsigned char* mb, unsigned qs, unsigned drop_thr, float drop_scale,
-                                              unsigned short* keep_out = nullptr) {
+                                              const unsigned char* mb, unsigned qs, unsigned drop_thr,
+                                              unsigned* keep_out = nullptr) {
     if (check) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -165,10 +168,11 @@ __device__ __forceinline__ void softmax_block(bool check, f32x16& s, f32x16& o, 
         const f32x2v a2 = a4.lo + a4.hi;
         l_run += a2.x + a2.y;
     }
-    if (DROPC < 0 ? drop_thr != 0 : DROPC > 0) {   // dropout acts on the normalised probabilities: the row sum above stays undropped
+    // dropout acts on the normalised probabilities: the row sum above stays undropped, and the factor 1 / (1 - p) of the
+    // kept ones is applied once, to the finished output rows
+    if (DROPC < 0 ? drop_thr != 0 : DROPC > 0) {
         // keys of accumulator elements (e, e + 1), e even: key0 + 4h + r, r = acc_row(e, 0) even, and r + 1
         const unsigned x0 = qs ^ (unsigned)(key0 + 4 * h);   // low 16 bits: key
-        s = s * drop_scale;
         unsigned long long keep[16];               // lane masks of the comparisons
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
@@ -179,11 +183,15 @@ __device__ __forceinline__ void softmax_block(bool check, f32x16& s, f32x16& o, 
             s[e] = k0 ? s[e] : 0.f;
             s[e + 1] = k1 ? s[e + 1] : 0.f;
         }
-        if ((DROPC < 0 || DROPC == 2) && keep_out) {   // a backward follows: the 16 bits, element 0 at bit 15
-            unsigned packed = 0;
+        if ((DROPC < 0 || DROPC == 2) && keep_out) {   // a backward follows
+            unsigned packed = 0;                       // element e at bit e: nibble j holds keys 8j + 4h .. + 3
 #pragma unroll
-            for (int e = 0; e < 16; ++e) push_bit(packed, keep[e]);
-            keep_out[(key0 >> 5) * 64] = (unsigned short)packed;
+            for (int e = 15; e >= 0; --e) push_bit(packed, keep[e]);
+            packed = (packed | (packed << 8)) & 0x00ff00ffu;
+            packed = (packed | (packed << 4)) & 0x0f0f0f0fu;       // nibble j now in the low half of byte j
+            packed <<= 4 * h;
+            packed |= __shfl_xor(packed, 32);          // the keys of the other lane half
+            if (h == 0) keep_out[(key0 >> 5) * 32] = packed;
         }
     }
 }
@@ -225,10 +233,11 @@ __device__ __forceinline__ void mha_fwd_body(const MhaFwdArgs& A, int bx, int he
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    // this lane's 16-bit slot of the keep-bit words of its query (null: no backward follows, or a query past the end)
-    unsigned short* const keep_lane = A.keep_bits && qok
-        ? reinterpret_cast<unsigned short*>(A.keep_bits + ((long)b * H + head) * attn_bits_words(Lq, Lk) +
-                                            (long)(q >> 5) * ((Lk + 31) / 32) * 32 + (q & 31)) + h
+    // the keep-bit word of this lane's query in the first key tile (null: no backward follows, or the wave's queries all
+    // lie past the end)
+    unsigned* const keep_lane = A.keep_bits && (q & ~31) < Lq
+        ? A.keep_bits + ((long)b * H + head) * attn_bits_words(Lq, Lk) + (long)(q >> 5) * ((Lk + 31) / 32) * 32 +
+              attn_bits_slot(q & 31)
         : nullptr;
 
     const float* Kb = K + (long)b * Lk * ldk + head * DH;
@@ -286,7 +295,7 @@ __device__ __forceinline__ void mha_fwd_body(const MhaFwdArgs& A, int bx, int he
                 mma(kf, qf, s);
             }
             // ---- mask, online softmax (per lane = per query)
-            softmax_block(mb || key0 + 32 > Lk, s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale, keep_lane);
+            softmax_block(mb || key0 + 32 > Lk, s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, keep_lane);
             // ---- O^T += V^T P^T   (reduction slot e of half h is key acc_row(e,h): the S^T accumulator IS the operand)
             {
                 Frag<BF16> vf, pf;
@@ -300,12 +309,14 @@ __device__ __forceinline__ void mha_fwd_body(const MhaFwdArgs& A, int bx, int he
     }
     // each half summed its own 16 keys per block
     const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float kept_scale = drop_thr ? drop_scale : 1.f;
     if (part_o) {                // this key range's unnormalised sums, its running maximum (log2 domain) and row sum
         if (qok) {
             float* op = part_o + (((long)split * nb + b) * Lq + q) * ((long)H * DH) + head * DH;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
-                *reinterpret_cast<float4*>(op + 8 * gq + 4 * h) = make_float4(o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]);
+                *reinterpret_cast<float4*>(op + 8 * gq + 4 * h) =
+                    make_float4(o[4 * gq] * kept_scale, o[4 * gq + 1] * kept_scale, o[4 * gq + 2] * kept_scale, o[4 * gq + 3] * kept_scale);
             if (h == 0) {
                 float* mp = part_ml + ((((long)split * nb + b) * H + head) * Lq + q) * 2;
                 mp[0] = m_run;
@@ -314,7 +325,7 @@ __device__ __forceinline__ void mha_fwd_body(const MhaFwdArgs& A, int bx, int he
         }
         return;
     }
-    const float inv = 1.f / l_tot;
+    const float inv = kept_scale / l_tot;
     if (qok) {
         float* op = O + ((long)b * Lq + q) * ldo + head * DH;
 #pragma unroll
@@ -375,9 +386,9 @@ __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    unsigned short* const keep_lane = keep_bits && qok
-        ? reinterpret_cast<unsigned short*>(keep_bits + ((long)b * H + head) * attn_bits_words(Lq, Lk) +
-                                            (long)(q >> 5) * ((Lk + 31) / 32) * 32 + (q & 31)) + h
+    unsigned* const keep_lane = keep_bits && (q & ~31) < Lq
+        ? keep_bits + ((long)b * H + head) * attn_bits_words(Lq, Lk) + (long)(q >> 5) * ((Lk + 31) / 32) * 32 +
+              attn_bits_slot(q & 31)
         : nullptr;
 
     const unsigned char* mb = kpm ? kpm + (long)b * Lk : nullptr;
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
     };
     auto softmax = [&](int j, f32x16& s) {
         const int key0 = j * 32;
-        softmax_block<DROPC>(mb || key0 + 32 > Lk, s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, drop_scale, keep_lane);
+        softmax_block<DROPC>(mb || key0 + 32 > Lk, s, o, m_run, l_run, key0, h, Lk, mb, qs, drop_thr, keep_lane);
     };
 
     fetch(0);
@@ -453,7 +464,7 @@ __global__ __launch_bounds__(512) void mha_fwd_pp_kernel(
     }
     if (!grp) __syncthreads();
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.f / l_tot;
+    const float inv = (DROPC ? drop_scale : 1.f) / l_tot;
     if (qok) {
         float* op = O + ((long)b * Lq + q) * ldo + head * DH;
 #pragma unroll
@@ -553,7 +564,8 @@ __global__ __launch_bounds__(256) void mha_clear_dq_kernel(float* __restrict__ d
 }
 
 // DROP: 0 = no attention dropout (the loop carries none of it), 1 = the mask is regenerated from the pair hash,
-// 2 = the mask is read from the keep bits the forward pass wrote (two instructions per element instead of the hash)
+// 2 = the mask is read from the keep bits the forward pass wrote (scalar loads and one select per element instead of
+// the hash).  The factor 1 / (1 - p) of the kept probabilities rides on the V fragment (dP) and on the final dV.
 template <bool BF16, int DROP>
 __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk, const float* __restrict__ V, long ldv,
@@ -561,9 +573,8 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const unsigned char* __restrict__ kpm, float* __restrict__ dQ, long lddq, float* __restrict__ dK, long lddk,
     float* __restrict__ dV, long lddv, int Lq, int Lk, int H, float scale, unsigned drop_thr, unsigned drop_seed,
     float drop_scale, const unsigned* __restrict__ keep_bits) {
-    // LDS: 2 x (Q tile, dO tile) [32][QP], 2 x (lse, delta) [32], K tile [128][QP], 2 x 4 x dS/dQ patch [32][QP],
-    //      2 x keep-bit words [4 waves][32 queries]
-    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * QP + 4 * 32 + 128 * QP + 2 * 4 * 32 * QP + (DROP == 2 ? 2 * 128 : 0)];
+    // LDS: 2 x (Q tile, dO tile) [32][QP], 2 x (lse, delta) [32], K tile [128][QP], 2 x 4 x dS/dQ patch [32][QP]
+    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * QP + 4 * 32 + 128 * QP + 2 * 4 * 32 * QP];
     auto Qs = [&](int buf) { return lds + buf * 32 * QP; };
     auto Gs = [&](int buf) { return lds + (2 + buf) * 32 * QP; };
     auto Ls = [&](int buf) { return lds + 4 * 32 * QP + buf * 64; };
@@ -571,7 +582,6 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     float* Kt = lds + 4 * 32 * QP + 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     float* const patches = Kt + 128 * QP;       // [2 sets][4 waves][32][QP]
-    unsigned* const Ms = reinterpret_cast<unsigned*>(patches + 2 * 4 * 32 * QP);     // [2][4 waves][32 queries] (DROP == 2)
 
     const int head = blockIdx.y, b = blockIdx.z;
     const int key_w0 = blockIdx.x * 128 + wave * 32;
@@ -579,11 +589,19 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     const float c = scale * 1.4426950408889634f;   // folded into the K fragment: scores come out in the log2 domain
     const unsigned ks = attn_stream_key(drop_seed, (unsigned)(b * H + head)) ^ (unsigned)(key & ~1);
     const unsigned half_shift = (key & 1) ? 0u : 16u, thr_hi = drop_thr << 16;
-    // keep bits: where this lane's key sits in a query's word (see attn_bits_words), and this workgroup's words
-    const unsigned keep_pos = 16u * ((l31 >> 2) & 1) + 15u - ((l31 & 3) + 4 * (l31 >> 3));
+    // keep bits: the words of this wave's key tile (see attn_bits_words), two per accumulator element and query tile;
+    // a wave whose keys all lie past the end reads the last tile's (its probabilities are zero anyway)
     const int nkt = (Lk + 31) / 32;
-    const unsigned* Mb = DROP == 2 ? keep_bits + ((long)b * H + head) * attn_bits_words(Lq, Lk) : nullptr;
-    unsigned sm = 0;
+    const unsigned long long* const Mw = DROP == 2
+        ? reinterpret_cast<const unsigned long long*>(
+              keep_bits + ((long)b * H + head) * attn_bits_words(Lq, Lk) +
+              (long)min((int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave), nkt - 1) * 32)
+        : nullptr;
+    unsigned long long km[16];
+    auto load_masks = [&](int t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) km[e] = Mw[(long)t * nkt * 16 + e];
+    };
 
     const float* Qb = Q + (long)b * Lq * ldq + head * DH;
     const float* Gb = dO + (long)b * Lq * lddo + head * DH;
@@ -602,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
     Frag<BF16> vf, kf;
     const bool kvalid = key < Lk;
     const bool kdead = !kvalid || (kpm && kpm[(long)b * Lk + key]);
-    load_frag(vf, V + ((long)b * Lk + (kvalid ? key : 0)) * ldv + head * DH + 16 * h, kvalid ? 1.f : 0.f);
+    load_frag(vf, V + ((long)b * Lk + (kvalid ? key : 0)) * ldv + head * DH + 16 * h, kvalid ? (DROP ? drop_scale : 1.f) : 0.f);
     float4 sq, sg, so;
     float sl = 0.f;
     auto fetch = [&](int t) {
@@ -620,10 +638,6 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
             const int qq = t * 32 + tid;
             sl = qq < Lq ? -(Lb[qq] * 1.4426950408889634f) : -INFINITY;      // the score accumulator starts at -LSE
         }
-        if (DROP == 2 && tid >= 128) {          // word of (key tile 4 bx + w, query t * 32 + i), w = (tid - 128) / 32
-            const int kt = blockIdx.x * 4 + ((tid - 128) >> 5), qq = t * 32 + (tid & 31);
-            sm = kt < nkt && qq < Lq ? Mb[((long)t * nkt + kt) * 32 + (tid & 31)] : 0u;
-        }
     };
     auto stash = [&](int buf) {
         *reinterpret_cast<float4*>(Qs(buf) + (tid >> 3) * QP + ((tid & 7) << 2)) = sq;
@@ -636,7 +650,6 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
         dsum += __shfl_xor(dsum, 2);
         dsum += __shfl_xor(dsum, 4);
         if ((tid & 7) == 0) Ds(buf)[tid >> 3] = DROP ? dsum : -dsum;          // without dropout dP starts at -delta
-        if (DROP == 2 && tid >= 128) Ms[buf * 128 + tid - 128] = sm;
     };
     fetch(0);
     stash(0);
@@ -687,6 +700,14 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
             Frag<BF16> qf, gf;
             load_frag(qf, qs + l31 * QP + 16 * h);
             load_frag(gf, gs + l31 * QP + 16 * h);
+            if (DROP == 2) {
+                // The scalar loads of this tile's masks go out once the LDS reads above have landed and come back
+                // under the 32 matrix instructions below: scalar loads and LDS reads share a counter that cannot tell
+                // them apart, so a scalar load in flight would turn every wait for an LDS read into a wait for it.
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_sched_barrier(0);
+                load_masks(t);
+            }
             mma(qf, kf, s);
             mma(gf, vf, dp);
         }
@@ -699,31 +720,23 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
             for (int e = 0; e < 16; ++e) s[e] = kdead ? 0.f : s[e];
         }
         if (DROP) {
-            f32x16 ms;                                  // the mask times 1 / (1 - p): 0 or drop_scale per element
+            f32x16 pm;                                  // the kept probabilities (their factor 1 / (1 - p) is in dP and dV)
             if (DROP == 2) {
-                const unsigned scale_bits = __float_as_uint(drop_scale);
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const uint4 w4 = *reinterpret_cast<const uint4*>(Ms + cur * 128 + wave * 32 + 8 * g4 + 4 * h);
-                    const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
-                    // 0 or all ones from this key's bit of the query's word, then the scale or 0
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        ms[4 * g4 + i] = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)w[i], keep_pos, 1u) & scale_bits);
-                }
+                for (int e = 0; e < 16; ++e) pm[e] = __builtin_amdgcn_inverse_ballot_w64(km[e]) ? s[e] : 0.f;
             } else {
                 const unsigned x0 = ks ^ ((unsigned)(t * 32 + 4 * h) << 16);     // query index sits in the high half
                 // the pair hash of (query, key & ~1): an odd key reads its high half; an even key's low half is moved up,
                 // and the comparison runs on the upper 16 bits (the threshold's lower 16 are zero)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    ms[e] = (attn_mix(x0 ^ ((unsigned)acc_row(e, 0) << 16)) << half_shift) >= thr_hi ? drop_scale : 0.f;
+                    pm[e] = (attn_mix(x0 ^ ((unsigned)acc_row(e, 0) << 16)) << half_shift) >= thr_hi ? s[e] : 0.f;
             }
             // dropped probabilities feed dV; dS = P (M dP - delta) = (P M) dP - P delta, in packed operations
             f32x16 dlv;
 #pragma unroll
             for (int e = 0; e < 16; ++e) dlv[e] = dl[e];
-            const f32x16 pm = s * ms, pd = s * dlv;
+            const f32x16 pd = s * dlv;
             dp = pm * dp - pd;
             s = pm;
         } else {
@@ -782,7 +795,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(
         const int kr = key_w0 + acc_row(e, h);
         if (kr < Lk) {
             dK[((long)b * Lk + kr) * lddk + head * DH + l31] = dk[e] * scale;
-            dV[((long)b * Lk + kr) * lddv + head * DH + l31] = dv[e];
+            dV[((long)b * Lk + kr) * lddv + head * DH + l31] = DROP ? dv[e] * drop_scale : dv[e];
         }
     }
 }
@@ -804,6 +817,7 @@ static int mha_bwd_impl(bool bf16, const float* q, long ldq, const float* k, lon
     SPOT_CHECK_ARG(B <= 65535 && nhead <= 65535, "mha_bwd: B and heads must fit a grid dimension");
     SPOT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "mha_bwd: drop_p=%f outside [0,1)", drop_p);
     SPOT_CHECK_ARG(drop_p == 0.f || (Lq <= 65536 && Lk <= 65536), "mha_bwd: dropout needs Lq, Lk <= 65536");
+    SPOT_CHECK_ARG(((uintptr_t)drop_bits & 7) == 0, "mha_bwd: drop_bits must be 8-byte aligned");
     if (B == 0) return SPOT_OK;
     // dQ is accumulated atomically: its [B*Lq, nhead*32] window is cleared first
     SPOT_CHECK_ARG(lddq % 4 == 0 && ((uintptr_t)dq & 15) == 0, "mha_bwd: dq must be 16-byte aligned with a row stride that is a multiple of 4");

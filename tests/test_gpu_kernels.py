@@ -508,7 +508,7 @@ def test_mha_core_dropout_matches_explicit_mask(ops):
                                         (160, 96, True)])
 def test_mha_keep_bits_from_the_forward_give_the_backward_of_the_regenerated_mask(ops, Lq, Lk, bf16):
     """A forward with dropout that also writes its keep bits returns the same output, the bits are the byte mask
-    (query-tile / key-tile words in the forward lanes' order), and a backward that reads them equals the backward that
+    (one word per query and key tile, key k at bit k, queries in the backward's row order), and a backward that reads them equals the backward that
     regenerates the mask from the seed: dK and dV bit for bit, dQ up to the order of its atomic adds."""
     from spot_amd import lib as L
     B, nh, dh, p, seed = (2, 4, 32, 0.2, 977) if Lq * Lk < 200000 else (8, 8, 32, 0.1, 31)
@@ -527,8 +527,8 @@ def test_mha_keep_bits_from_the_forward_give_the_backward_of_the_regenerated_mas
     nqt, nkt = (Lq + 31) // 32, (Lk + 31) // 32
     words = keep.view(B, nh, nqt, nkt, 32).cpu().numpy().astype(np.uint32)
     r = np.arange(32)
-    pos = 16 * ((r >> 2) & 1) + 15 - ((r & 3) + 4 * (r >> 3))          # bit of key r (within its tile) in a query's word
-    got = ((words[..., None] >> pos.astype(np.uint32)) & 1).astype(np.uint8)      # [B, nh, nqt, nkt, 32 q, 32 keys]
+    slot = 2 * ((r & 3) + 4 * (r >> 3)) + ((r >> 2) & 1)               # where the word of query r (within its tile) sits
+    got = ((words[..., slot, None] >> r.astype(np.uint32)) & 1).astype(np.uint8)  # [B, nh, nqt, nkt, 32 q, 32 keys]
     got = got.transpose(0, 1, 2, 4, 3, 5).reshape(B, nh, nqt * 32, nkt * 32)[:, :, :Lq, :Lk]
     assert np.array_equal(got, mask.cpu().numpy())
     P = ops._p
